@@ -1,0 +1,234 @@
+"""ctypes view of the C ABI in include/hjd.h (libhjd.so: HIP kernels for gfx950 + host runtime).
+
+The package directory name carries a hyphen (it mirrors the reference repo's name), so import it
+with importlib:  hjd = importlib.import_module("hls-jpeg-decoder_amd").
+
+Everything here is plumbing; the decode runs in the HIP kernels.  If libhjd.so is missing or no
+HIP device is usable the calls fail loudly — there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhjd.so")
+
+HJD_OK, HJD_ERR_NOT_JPEG, HJD_ERR_UNSUPPORTED, HJD_ERR_CORRUPT, HJD_ERR_DIRTY_RESTART, HJD_ERR_NO_DEVICE, \
+    HJD_ERR_ARG, HJD_ERR_IO, HJD_ERR_INTERNAL = range(9)
+OUT_RGB, OUT_BMP = 0, 1
+MAX_STAGES = 16
+
+# every symbol include/hjd.h declares
+EXPORTS = [
+    "hjd_status_string", "hjd_last_status", "hjd_convert_jpg_file", "hjd_decode_jpg_file_data", "hjd_free",
+    "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
+    "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
+    "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
+    "hjd_batch_run_timed", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
+]
+
+
+class HuffSpec(ctypes.Structure):
+    _fields_ = [("defined", ctypes.c_uint8), ("bits", ctypes.c_uint8 * 17), ("vals", ctypes.c_uint8 * 256)]
+
+
+class JpegData(ctypes.Structure):
+    _fields_ = [("qtable", (ctypes.c_uint8 * 64) * 4), ("dc_table_index", ctypes.c_uint8 * 4),
+                ("ac_table_index", ctypes.c_uint8 * 4), ("htdc", HuffSpec * 4), ("htac", HuffSpec * 4),
+                ("stream", ctypes.c_void_p), ("stream_len", ctypes.c_size_t), ("restart_interval", ctypes.c_int),
+                ("restart_mcus", ctypes.c_uint), ("width", ctypes.c_uint), ("height", ctypes.c_uint),
+                ("hfactor", ctypes.c_uint8), ("vfactor", ctypes.c_uint8), ("header_bytes", ctypes.c_size_t)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("subseq_bits", ctypes.c_int), ("sync_launches", ctypes.c_int), ("reserved", ctypes.c_int * 6)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libhjd.so (build it with `make lib` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libhjd.so not built (%s): run `make lib`; there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ip, sz = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t
+    L.hjd_status_string.restype = ctypes.c_char_p
+    L.hjd_status_string.argtypes = [ctypes.c_int]
+    L.hjd_last_status.restype = ctypes.c_int
+    L.hjd_convert_jpg_file.restype = ctypes.c_int
+    L.hjd_convert_jpg_file.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.hjd_decode_jpg_file_data.restype = ctypes.c_int
+    L.hjd_decode_jpg_file_data.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(vp),
+                                           ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    L.hjd_free.restype = None
+    L.hjd_free.argtypes = [vp]
+    L.hjd_parse_header.restype = ctypes.c_int
+    L.hjd_parse_header.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(JpegData)]
+    L.hjd_jpeg_decode_hw.restype = ctypes.c_int
+    L.hjd_jpeg_decode_hw.argtypes = [ctypes.POINTER(JpegData), ctypes.c_uint, ctypes.c_uint, ctypes.c_ubyte,
+                                     ctypes.c_ubyte, vp]
+    L.hjd_decoder_create.restype = vp
+    L.hjd_decoder_create.argtypes = [ctypes.c_int, ctypes.POINTER(Options)]
+    L.hjd_decoder_destroy.restype = None
+    L.hjd_decoder_destroy.argtypes = [vp]
+    L.hjd_device_count.restype = ctypes.c_int
+    L.hjd_batch_prepare.restype = vp
+    L.hjd_batch_prepare.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
+                                    ctypes.c_int, ip]
+    L.hjd_batch_destroy.restype = None
+    L.hjd_batch_destroy.argtypes = [vp]
+    L.hjd_batch_run.restype = ctypes.c_int
+    L.hjd_batch_run.argtypes = [vp, vp]
+    L.hjd_batch_finish.restype = ctypes.c_int
+    L.hjd_batch_finish.argtypes = [vp, vp, ip]
+    L.hjd_batch_image_info.restype = ctypes.c_int
+    L.hjd_batch_image_info.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
+                                       ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.hjd_batch_out_device_ptr.restype = vp
+    L.hjd_batch_out_device_ptr.argtypes = [vp]
+    L.hjd_batch_out_bytes.restype = sz
+    L.hjd_batch_out_bytes.argtypes = [vp]
+    L.hjd_batch_download.restype = ctypes.c_int
+    L.hjd_batch_download.argtypes = [vp, ctypes.c_int, vp, sz]
+    L.hjd_batch_download_coefs.restype = ctypes.c_int
+    L.hjd_batch_download_coefs.argtypes = [vp, ctypes.c_int, vp, sz]
+    L.hjd_batch_totals.restype = ctypes.c_int
+    L.hjd_batch_totals.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                   ctypes.POINTER(ctypes.c_uint64)]
+    L.hjd_batch_run_timed.restype = ctypes.c_int
+    L.hjd_batch_run_timed.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p),
+                                      ctypes.c_int]
+    L.hjd_decode_batch_host.restype = ctypes.c_int
+    L.hjd_bmp_bytes.restype = sz
+    L.hjd_bmp_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    L.hjd_rgb_bytes.restype = sz
+    L.hjd_rgb_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    _lib = L
+    return L
+
+
+def status_string(s):
+    return lib().hjd_status_string(int(s)).decode()
+
+
+def parse_header(jpg):
+    """hjd_parse_header -> (status, JpegData).  JpegData.stream points into `jpg` (keep it alive)."""
+    jd = JpegData()
+    return lib().hjd_parse_header(jpg, len(jpg), ctypes.byref(jd)), jd
+
+
+class Decoder:
+    """hjd_decoder: one per (process, device)."""
+
+    def __init__(self, device=0, subseq_bits=0, sync_launches=0):
+        opt = Options(subseq_bits, sync_launches)
+        self._h = lib().hjd_decoder_create(device, ctypes.byref(opt))
+        if not self._h:
+            raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))
+
+    def close(self):
+        if self._h:
+            lib().hjd_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def prepare(self, jpgs, out_format=OUT_RGB):
+        return Batch(self, jpgs, out_format)
+
+    def decode(self, jpgs, out_format=OUT_RGB):
+        """Decode a list of JPEG byte strings.  Returns (statuses, outputs): outputs[i] is a numpy array
+        (h, w, 3) for RGB, a bytes-like uint8 array for BMP, or None when statuses[i] != 0."""
+        b = self.prepare(jpgs, out_format)
+        try:
+            b.run()
+            st = b.finish()
+            outs = [b.download(i) if st[i] == HJD_OK else None for i in range(len(jpgs))]
+            return st, outs
+        finally:
+            b.close()
+
+
+class Batch:
+    def __init__(self, dec, jpgs, out_format):
+        self._dec = dec
+        self._jpgs = list(jpgs)  # keep alive while preparing
+        self.n = len(self._jpgs)
+        self.out_format = out_format
+        arr = (ctypes.c_char_p * self.n)(*self._jpgs)
+        lens = (ctypes.c_size_t * self.n)(*[len(j) for j in self._jpgs])
+        st = (ctypes.c_int * self.n)()
+        self._h = lib().hjd_batch_prepare(dec._h, self.n, arr, lens, out_format, st)
+        if not self._h:
+            raise RuntimeError("hjd_batch_prepare failed: %s" % status_string(lib().hjd_last_status()))
+        self.parse_status = list(st)
+
+    def close(self):
+        if self._h:
+            lib().hjd_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, stream=None):
+        rc = lib().hjd_batch_run(self._h, stream)
+        if rc:
+            raise RuntimeError("hjd_batch_run: %s" % status_string(rc))
+
+    def finish(self, stream=None):
+        st = (ctypes.c_int * self.n)()
+        rc = lib().hjd_batch_finish(self._h, stream, st)
+        if rc:
+            raise RuntimeError("hjd_batch_finish: %s" % status_string(rc))
+        return list(st)
+
+    def run_timed(self, stream=None):
+        ms = (ctypes.c_float * MAX_STAGES)()
+        names = (ctypes.c_char_p * MAX_STAGES)()
+        n = lib().hjd_batch_run_timed(self._h, stream, ms, names, MAX_STAGES)
+        if n < 0:
+            raise RuntimeError("hjd_batch_run_timed failed")
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def info(self, i):
+        w, h = ctypes.c_uint(), ctypes.c_uint()
+        off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+        rc = lib().hjd_batch_image_info(self._h, i, ctypes.byref(w), ctypes.byref(h), ctypes.byref(off), ctypes.byref(nb))
+        return rc, w.value, h.value, off.value, nb.value
+
+    def totals(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        lib().hjd_batch_totals(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return a.value, b.value, c.value
+
+    def out_device_ptr(self):
+        return lib().hjd_batch_out_device_ptr(self._h), lib().hjd_batch_out_bytes(self._h)
+
+    def download(self, i):
+        rc, w, h, off, nb = self.info(i)
+        if rc:
+            raise RuntimeError("image %d: %s" % (i, status_string(rc)))
+        buf = np.empty(nb, np.uint8)
+        rc = lib().hjd_batch_download(self._h, i, buf.ctypes.data, nb)
+        if rc:
+            raise RuntimeError("hjd_batch_download: %s" % status_string(rc))
+        return buf.reshape(h, w, 3) if self.out_format == OUT_RGB else buf
+
+    def download_coefs(self, i, nblocks):
+        buf = np.empty((nblocks, 64), np.int16)
+        rc = lib().hjd_batch_download_coefs(self._h, i, buf.ctypes.data, buf.size)
+        if rc:
+            raise RuntimeError("hjd_batch_download_coefs: %s" % status_string(rc))
+        return buf
+
+
+def convert_jpg_file(jpg_path, bmp_path):
+    """ConvertJpgFile (openjpg.h:23): 1 on success, 0 on failure."""
+    return lib().hjd_convert_jpg_file(os.fsencode(jpg_path), os.fsencode(bmp_path))

@@ -1,0 +1,90 @@
+// hjd_device.h — data layout shared by the host runtime and the gfx950 kernels.
+//
+// Everything a kernel reads lives in HBM slabs owned by a batch:
+//   raw      : the stuffed scan bytes of all images, image i at raw_off (16-B aligned, padded)
+//   ustream  : the unstuffed scans as MSB-first 32-bit words (byte k of the bit string is
+//              stored at address k^3), image i at ustream_off
+//   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
+//   substart : exclusive prefix sums over sub (first block index, DC predictors)
+//   coef     : dense int16 coefficients, zig-zag order, 64 per block
+//   out      : RGB or BMP bytes
+#pragma once
+#include <stdint.h>
+
+#define HJD_LUT_BITS 10
+#define HJD_LUT_SIZE (1 << HJD_LUT_BITS)
+#define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
+#define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
+#define HJD_SYNC_WG 256        // subsequences per synchronisation workgroup
+#define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
+
+// Huffman decode tables of one distinct (DC/AC x 3 components) configuration.
+// lut entry (u16): bits 0-4 code length (0 = longer than HJD_LUT_BITS -> slow path),
+// bits 5-8 number of value bits s, bits 9-15 zig-zag advance:
+//   DC symbol n          -> s = n, adv = 1
+//   AC (r,s>0)           -> adv = r + 1 (coefficient lands at z + r)
+//   AC EOB (0,0)         -> adv = 64;  ZRL (15,0) -> adv = 16;  other (r,0) -> adv = 0
+//   (loadjpg.cpp:768-808)
+struct HjdTableSet {
+    uint16_t lut[HJD_SLOTS][HJD_LUT_SIZE];
+    uint16_t mincode[HJD_SLOTS][17]; // canonical slow path: first code of length k
+    uint16_t count[HJD_SLOTS][17];   // number of codes of length k
+    uint16_t first[HJD_SLOTS][17];   // index of the first symbol of length k
+    uint16_t sym_entry[HJD_SLOTS][256]; // (s | adv << 4) per symbol index, same meaning as the lut fields
+};
+
+struct HjdImage {
+    uint32_t width, height;
+    uint32_t hf, vf;        // luma sampling factors
+    uint32_t nby;           // hf*vf luma blocks per MCU
+    uint32_t nb;            // nby + 2 blocks per MCU
+    uint32_t mcux, mcuy;    // MCU grid (loadjpg.cpp:1170-1182)
+    uint32_t nblocks;       // mcux*mcuy*nb
+    uint32_t scan_len;      // raw scan bytes
+    uint32_t tabset;        // index into the HjdTableSet array
+    uint32_t chunk0;        // first unstuff chunk (global numbering)
+    uint32_t nchunks;
+    uint32_t sub0;          // first subsequence (global numbering, capacity-based)
+    uint32_t nsub_cap;      // capacity: ceil(scan_len*8 / subseq_bits)
+    uint32_t syncwg0;       // first synchronisation workgroup
+    uint32_t nsyncwg;
+    uint32_t group0;        // first IDCT/colour workgroup
+    uint32_t groups_per_row;
+    uint32_t ngroups;
+    uint32_t out_stride;    // bytes per output row (3W, or BMP padded)
+    uint32_t out_format;    // 0 RGB, 1 BMP
+    uint64_t raw_off;       // byte offset into raw slab
+    uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
+    uint64_t coef_off;      // element offset into coef slab
+    uint64_t out_off;       // byte offset into out slab
+    uint8_t qt[3][64];      // dequantisation tables as USED per component (Cb already holds Cr's), zig-zag order
+};
+
+// per image, written by the kernels
+struct HjdImageState {
+    uint32_t ustream_len;   // unstuffed bytes
+    uint32_t flags;         // HJD_FLAG_*
+    uint32_t total_blocks;  // blocks completed over all subsequences
+    uint32_t pad;
+};
+#define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
+#define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)
+#define HJD_FLAG_NOT_CONVERGED 4u // a subsequence was decoded from a stale start state
+#define HJD_FLAG_SHORT 8u         // stream ended before all blocks were decoded
+
+// synchronisation record of one subsequence
+struct HjdSub {
+    uint32_t e_p;    // end state: absolute bit position (>= end of this subsequence)
+    uint32_t e_zm;   // end state: z | m << 8
+    uint32_t u_p;    // start state this record was computed from
+    uint32_t u_zm;
+    uint32_t nblk;   // blocks completed inside
+    int16_t dc[3];   // sum of DC differences decoded inside, per component (mod 2^16)
+    int16_t pad;
+};
+
+struct HjdSubStart {
+    uint32_t blk0;   // index of the block in progress at the subsequence start
+    int16_t pred[3]; // DC predictors at the subsequence start
+    int16_t pad;
+};

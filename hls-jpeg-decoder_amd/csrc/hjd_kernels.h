@@ -1,0 +1,27 @@
+// hjd_kernels.h — kernel argument bundle and launch entry points (host <-> hjd_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hjd_device.h"
+
+struct HjdParams {
+    const HjdImage *img;       // [nimg]
+    HjdImageState *st;         // [nimg]
+    const HjdTableSet *tabs;   // distinct Huffman configurations
+    const uint8_t *raw;        // stuffed scans
+    uint8_t *ustream;          // unstuffed scans, MSB-first words
+    uint32_t *chunk_kept;      // kept bytes per unstuff chunk
+    HjdSub *sub;               // per subsequence
+    HjdSubStart *substart;     // per subsequence
+    int16_t *coef;             // dense coefficients
+    uint8_t *out;              // RGB / BMP bytes
+    int nimg;
+    uint32_t subseq_bits;
+};
+
+int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
+int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int launch_idx, hipStream_t s);
+int hjd_launch_scan(const HjdParams &P, hipStream_t s);
+int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
+int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

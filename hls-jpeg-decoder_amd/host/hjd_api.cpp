@@ -1,0 +1,633 @@
+// hjd_api.cpp — device runtime behind the C ABI (include/hjd.h): batch layout in HBM, table
+// construction, kernel sequencing on a HIP stream, status collection.  The decode itself is the
+// kernels in csrc/hjd_kernels.hip; there is no host fallback.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hjd.h"
+#include "../csrc/hjd_kernels.h"
+#include "hjd_internal.h"
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "hjd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return HJD_ERR_INTERNAL;                                                              \
+        }                                                                                         \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct hjd_decoder {
+    int device = 0;
+    uint32_t subseq_bits = 1024;
+    int sync_launches = 2;
+};
+
+struct hjd_batch {
+    hjd_decoder *dec = nullptr;
+    int n = 0;                       // images offered
+    int nimg = 0;                    // images that parsed and are on the device
+    std::vector<int> parse_status;   // per offered image
+    std::vector<int> dev_index;      // offered image -> device image index or -1
+    std::vector<HjdImage> img;       // device images (host copy)
+    std::vector<size_t> out_bytes;   // per device image
+    std::vector<size_t> hdr_bytes;
+    std::vector<HjdImageState> state;
+    int out_format = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, ngroups = 0;
+    size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
+    uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
+    // device
+    HjdImage *d_img = nullptr;
+    HjdImageState *d_st = nullptr;
+    HjdTableSet *d_tabs = nullptr;
+    uint8_t *d_raw = nullptr, *d_ustream = nullptr, *d_out = nullptr;
+    uint32_t *d_chunk_kept = nullptr;
+    HjdSub *d_sub = nullptr;
+    HjdSubStart *d_substart = nullptr;
+    int16_t *d_coef = nullptr;
+    HjdParams P{};
+    hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
+    bool have_events = false;
+};
+
+// ---- Huffman table construction (GenHuffCodes / BuildHuffmanTable, openjpg.cpp:48-98) ----------
+
+static void build_slot(HjdTableSet &ts, int slot, const hjd_huff_spec &h, bool is_dc)
+{
+    memset(ts.lut[slot], 0, sizeof(ts.lut[slot]));
+    unsigned code = 0, idx = 0;
+    for (int k = 1; k <= 16; k++) {
+        ts.mincode[slot][k] = (uint16_t)code;
+        ts.count[slot][k] = h.bits[k];
+        ts.first[slot][k] = (uint16_t)idx;
+        for (unsigned j = 0; j < h.bits[k]; j++, idx++, code++) {
+            const unsigned sym = h.vals[idx];
+            unsigned s, adv;
+            if (is_dc) { // DC symbol = number of extra bits (loadjpg.cpp:616)
+                s = sym & 15;
+                adv = 1;
+            } else { // AC run/size (loadjpg.cpp:768-808)
+                s = sym & 15;
+                const unsigned r = sym >> 4;
+                if (s) adv = r + 1;
+                else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
+            }
+            ts.sym_entry[slot][idx] = (uint16_t)(s | (adv << 4));
+            if (k <= HJD_LUT_BITS) {
+                const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
+                const unsigned lo = code << (HJD_LUT_BITS - k), cnt = 1u << (HJD_LUT_BITS - k);
+                for (unsigned q = 0; q < cnt; q++) ts.lut[slot][lo + q] = e;
+            }
+        }
+        code <<= 1;
+    }
+    ts.mincode[slot][0] = ts.count[slot][0] = ts.first[slot][0] = 0;
+}
+
+static std::string tabset_key(const hjd_jpeg_data &j)
+{
+    std::string k;
+    for (int c = 1; c <= 3; c++) {
+        const hjd_huff_spec &d = j.htdc[j.dc_table_index[c]], &a = j.htac[j.ac_table_index[c]];
+        k.append((const char *)d.bits, 17).append((const char *)d.vals, 256);
+        k.append((const char *)a.bits, 17).append((const char *)a.vals, 256);
+    }
+    return k;
+}
+
+// ---- decoder ------------------------------------------------------------------------------------
+
+extern "C" int hjd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
+{
+    int n = hjd_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        hjd_set_last_status(HJD_ERR_NO_DEVICE);
+        fprintf(stderr, "hjd: no usable HIP device %d (found %d); this path has no CPU fallback\n", device, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        hjd_set_last_status(HJD_ERR_NO_DEVICE);
+        return nullptr;
+    }
+    hjd_decoder *d = new hjd_decoder();
+    d->device = device;
+    if (opt) {
+        if (opt->subseq_bits) {
+            if (opt->subseq_bits < 64 || opt->subseq_bits > 4096 || (opt->subseq_bits % 32)) {
+                delete d;
+                hjd_set_last_status(HJD_ERR_ARG);
+                return nullptr;
+            }
+            d->subseq_bits = (uint32_t)opt->subseq_bits;
+        }
+        if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
+    }
+    const char *e = getenv("HJD_SUBSEQ_BITS");
+    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && atoi(e) % 32 == 0) d->subseq_bits = (uint32_t)atoi(e);
+    return d;
+}
+
+extern "C" void hjd_decoder_destroy(hjd_decoder *d) { delete d; }
+
+// ---- batch --------------------------------------------------------------------------------------
+
+static void batch_free_device(hjd_batch *b)
+{
+    (void)hipFree(b->d_img);
+    (void)hipFree(b->d_st);
+    (void)hipFree(b->d_tabs);
+    (void)hipFree(b->d_raw);
+    (void)hipFree(b->d_ustream);
+    (void)hipFree(b->d_out);
+    (void)hipFree(b->d_chunk_kept);
+    (void)hipFree(b->d_sub);
+    (void)hipFree(b->d_substart);
+    (void)hipFree(b->d_coef);
+    if (b->have_events)
+        for (auto &e : b->ev) (void)hipEventDestroy(e);
+}
+
+extern "C" void hjd_batch_destroy(hjd_batch *b)
+{
+    if (!b) return;
+    batch_free_device(b);
+    delete b;
+}
+
+static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
+{
+    hjd_decoder *d = b->dec;
+    HIPCHK(hipSetDevice(d->device));
+    const uint32_t S = d->subseq_bits;
+    std::map<std::string, uint32_t> tab_index;
+    std::vector<HjdTableSet> tabs;
+    size_t raw_cur = 0, us_cur = 0, coef_cur = 0, out_cur = 0;
+
+    for (int i = 0; i < b->n; i++) {
+        b->dev_index[i] = -1;
+        if (b->parse_status[i] != HJD_OK) continue;
+        const hjd_jpeg_data &j = parsed[i];
+        if (j.restart_interval > 0) { // restart streams: handled by the interval path (not in this build)
+            b->parse_status[i] = HJD_ERR_UNSUPPORTED;
+            continue;
+        }
+        if (j.stream_len >= (1u << 28)) {
+            b->parse_status[i] = HJD_ERR_UNSUPPORTED;
+            continue;
+        }
+        HjdImage im;
+        memset(&im, 0, sizeof(im));
+        im.width = j.width;
+        im.height = j.height;
+        im.hf = j.hfactor;
+        im.vf = j.vfactor;
+        im.nby = im.hf * im.vf;
+        im.nb = im.nby + 2;
+        im.mcux = (im.width + 8 * im.hf - 1) / (8 * im.hf); // loadjpg.cpp:1170-1176 loop trip counts
+        im.mcuy = (im.height + 8 * im.vf - 1) / (8 * im.vf);
+        im.nblocks = im.mcux * im.mcuy * im.nb;
+        im.scan_len = (uint32_t)j.stream_len;
+        const std::string key = tabset_key(j);
+        auto it = tab_index.find(key);
+        if (it == tab_index.end()) {
+            HjdTableSet ts;
+            memset(&ts, 0, sizeof(ts));
+            for (int c = 1; c <= 3; c++) {
+                build_slot(ts, (c - 1) * 2 + 0, j.htdc[j.dc_table_index[c]], true);
+                build_slot(ts, (c - 1) * 2 + 1, j.htac[j.ac_table_index[c]], false);
+            }
+            it = tab_index.emplace(key, (uint32_t)tabs.size()).first;
+            tabs.push_back(ts);
+        }
+        im.tabset = it->second;
+        im.chunk0 = b->nchunks;
+        im.nchunks = (im.scan_len + HJD_UNSTUFF_CHUNK - 1) / HJD_UNSTUFF_CHUNK;
+        b->nchunks += im.nchunks;
+        im.sub0 = b->nsub;
+        im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
+        b->nsub += im.nsub_cap;
+        im.syncwg0 = b->nsyncwg;
+        im.nsyncwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
+        b->nsyncwg += im.nsyncwg;
+        im.group0 = b->ngroups;
+        im.groups_per_row = (im.mcux + HJD_GROUP_MCUS - 1) / HJD_GROUP_MCUS;
+        im.ngroups = im.groups_per_row * im.mcuy;
+        b->ngroups += im.ngroups;
+        im.out_format = (uint32_t)b->out_format;
+        size_t obytes;
+        if (b->out_format == HJD_OUT_BMP) {
+            im.out_stride = (im.width * 3 + 3) & ~3u;
+            obytes = hjd_bmp_bytes(im.width, im.height);
+            out_cur = align_up(out_cur, 256) + 2; // pixel rows start 54 bytes in: keep them 4-byte aligned
+        } else {
+            im.out_stride = im.width * 3;
+            obytes = hjd_rgb_bytes(im.width, im.height);
+            out_cur = align_up(out_cur, 256);
+        }
+        im.out_off = out_cur;
+        out_cur += obytes;
+        im.raw_off = raw_cur;
+        raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
+        im.ustream_off = us_cur;
+        us_cur += align_up((size_t)im.scan_len + 64, 256);
+        im.coef_off = coef_cur;
+        coef_cur += (size_t)im.nblocks * 64;
+        // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
+        memcpy(im.qt[0], j.qtable[1], 64);
+        memcpy(im.qt[1], j.qtable[3], 64);
+        memcpy(im.qt[2], j.qtable[3], 64);
+        b->dev_index[i] = (int)b->img.size();
+        b->img.push_back(im);
+        b->out_bytes.push_back(obytes);
+        b->hdr_bytes.push_back(j.header_bytes);
+        b->pixels += (uint64_t)im.width * im.height;
+        b->scan_bytes += im.scan_len;
+        b->alg_bytes += (uint64_t)im.scan_len + j.header_bytes + (uint64_t)im.width * im.height * 3;
+    }
+    b->nimg = (int)b->img.size();
+    b->raw_bytes = raw_cur;
+    b->ustream_bytes = us_cur;
+    b->coef_elems = coef_cur;
+    b->out_total = out_cur;
+    b->state.assign(b->nimg, HjdImageState{0, 0, 0, 0});
+    if (!b->nimg) return HJD_OK;
+
+    // upload
+    std::vector<uint8_t> raw(raw_cur, 0);
+    for (int i = 0; i < b->n; i++) {
+        int di = b->dev_index[i];
+        if (di < 0) continue;
+        memcpy(raw.data() + b->img[di].raw_off, parsed[i].stream, parsed[i].stream_len);
+    }
+    HIPCHK(hipMalloc(&b->d_img, sizeof(HjdImage) * b->nimg));
+    HIPCHK(hipMalloc(&b->d_st, sizeof(HjdImageState) * b->nimg));
+    HIPCHK(hipMalloc(&b->d_tabs, sizeof(HjdTableSet) * tabs.size()));
+    HIPCHK(hipMalloc(&b->d_raw, raw_cur));
+    HIPCHK(hipMalloc(&b->d_ustream, us_cur));
+    HIPCHK(hipMalloc(&b->d_out, out_cur ? out_cur : 4));
+    HIPCHK(hipMalloc(&b->d_chunk_kept, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
+    HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMalloc(&b->d_coef, sizeof(int16_t) * (coef_cur ? coef_cur : 1)));
+    HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(b->d_ustream, 0, us_cur));
+    HIPCHK(hipMemset(b->d_st, 0, sizeof(HjdImageState) * b->nimg));
+    HIPCHK(hipMemset(b->d_sub, 0, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
+
+    HjdParams &P = b->P;
+    P.img = b->d_img;
+    P.st = b->d_st;
+    P.tabs = b->d_tabs;
+    P.raw = b->d_raw;
+    P.ustream = b->d_ustream;
+    P.chunk_kept = b->d_chunk_kept;
+    P.sub = b->d_sub;
+    P.substart = b->d_substart;
+    P.coef = b->d_coef;
+    P.out = b->d_out;
+    P.nimg = b->nimg;
+    P.subseq_bits = S;
+    return HJD_OK;
+}
+
+static hjd_batch *batch_from_parsed(hjd_decoder *d, int n, const std::vector<hjd_jpeg_data> &parsed,
+                                    const std::vector<int> &pstatus, int out_format, int *status)
+{
+    hjd_batch *b = new hjd_batch();
+    b->dec = d;
+    b->n = n;
+    b->out_format = out_format;
+    b->parse_status = pstatus;
+    b->dev_index.assign(n, -1);
+    int rc = batch_build(b, parsed);
+    if (status)
+        for (int i = 0; i < n; i++) status[i] = b->parse_status[i];
+    if (rc != HJD_OK) {
+        hjd_set_last_status(rc);
+        hjd_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
+                                        int out_format, int *status)
+{
+    if (!d || n < 0 || (n && (!jpg || !jpg_len)) || (out_format != HJD_OUT_RGB && out_format != HJD_OUT_BMP)) {
+        hjd_set_last_status(HJD_ERR_ARG);
+        return nullptr;
+    }
+    std::vector<hjd_jpeg_data> parsed(n);
+    std::vector<int> pst(n);
+    for (int i = 0; i < n; i++) pst[i] = hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]);
+    return batch_from_parsed(d, n, parsed, pst, out_format, status);
+}
+
+// the kernel sequence; ev != nullptr records an event before each stage and one after the last
+static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nstage, const char **names)
+{
+    if (!b->nimg) {
+        if (nstage) *nstage = 0;
+        return HJD_OK;
+    }
+    const HjdParams &P = b->P;
+    int k = 0;
+    auto mark = [&](const char *name) -> int {
+        if (names) {
+            if (k < HJD_MAX_STAGES) {
+                names[k] = name;
+                if (hipEventRecord(b->ev[k], s) != hipSuccess) return HJD_ERR_INTERNAL;
+            }
+            k++;
+        }
+        return HJD_OK;
+    };
+    int rc;
+    if (!from_resync) {
+        if ((rc = mark("reset"))) return rc;
+        HIPCHK(hipMemsetAsync(b->d_st, 0, sizeof(HjdImageState) * b->nimg, s));
+        if ((rc = mark("unstuff"))) return rc;
+        if (hjd_launch_unstuff(P, b->nchunks, s)) return HJD_ERR_INTERNAL;
+        if ((rc = mark("huff_sync"))) return rc;
+        for (int l = 0; l < b->dec->sync_launches; l++)
+            if (hjd_launch_sync(P, b->nsyncwg, l, s)) return HJD_ERR_INTERNAL;
+    } else {
+        if (hjd_launch_sync(P, b->nsyncwg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, b->nsyncwg, 1, s)) return HJD_ERR_INTERNAL;
+    }
+    if ((rc = mark("scan"))) return rc;
+    if (hjd_launch_scan(P, s)) return HJD_ERR_INTERNAL;
+    if ((rc = mark("coef_clear"))) return rc;
+    HIPCHK(hipMemsetAsync(b->d_coef, 0, sizeof(int16_t) * b->coef_elems, s));
+    if ((rc = mark("huff_write"))) return rc;
+    if (hjd_launch_write(P, b->nsyncwg, s)) return HJD_ERR_INTERNAL;
+    if ((rc = mark("idct_color"))) return rc;
+    if (hjd_launch_idct_color(P, b->ngroups, s)) return HJD_ERR_INTERNAL;
+    if ((rc = mark("end"))) return rc;
+    if (nstage) *nstage = k;
+    return HJD_OK;
+}
+
+extern "C" int hjd_batch_run(hjd_batch *b, void *hip_stream)
+{
+    if (!b) return HJD_ERR_ARG;
+    return batch_enqueue(b, (hipStream_t)hip_stream, false, nullptr, nullptr);
+}
+
+extern "C" int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const char **stage_names, int cap)
+{
+    if (!b || !stage_ms || !stage_names) return -1;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (!b->have_events) {
+        for (auto &e : b->ev)
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+        b->have_events = true;
+    }
+    const char *names[HJD_MAX_STAGES + 1] = {};
+    int ns = 0;
+    if (batch_enqueue(b, s, false, &ns, names) != HJD_OK) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    int nout = 0;
+    for (int k = 0; k + 1 < ns && nout < cap; k++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]) != hipSuccess) return -1;
+        stage_ms[nout] = ms;
+        stage_names[nout] = names[k];
+        nout++;
+    }
+    return nout;
+}
+
+extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
+{
+    if (!b) return HJD_ERR_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int overall = HJD_OK;
+    if (b->nimg) {
+        // normally one pass; if the induction check failed somewhere, run more synchronisation
+        // launches (each propagates true states across one more workgroup boundary) and redo the output
+        for (int attempt = 0;; attempt++) {
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(b->state.data(), b->d_st, sizeof(HjdImageState) * b->nimg, hipMemcpyDeviceToHost));
+            bool stale = false;
+            for (auto &st : b->state) stale |= (st.flags & HJD_FLAG_NOT_CONVERGED) != 0;
+            if (!stale) break;
+            if (attempt >= 4096) {
+                overall = HJD_ERR_INTERNAL;
+                break;
+            }
+            for (auto &st : b->state) st.flags = 0;
+            // keep ustream_len, clear flags
+            std::vector<HjdImageState> tmp = b->state;
+            HIPCHK(hipMemcpyAsync(b->d_st, tmp.data(), sizeof(HjdImageState) * b->nimg, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            int rc = batch_enqueue(b, s, true, nullptr, nullptr);
+            if (rc) return rc;
+        }
+    }
+    for (int i = 0; i < b->n; i++) {
+        int st = b->parse_status[i];
+        const int di = b->dev_index[i];
+        if (st == HJD_OK && di >= 0) {
+            const uint32_t f = b->state[di].flags;
+            if (f & HJD_FLAG_NOT_CONVERGED) st = HJD_ERR_INTERNAL;
+            else if (f & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN | HJD_FLAG_SHORT)) st = HJD_ERR_CORRUPT;
+        }
+        if (status) status[i] = st;
+    }
+    return overall;
+}
+
+extern "C" int hjd_batch_image_info(const hjd_batch *b, int i, unsigned *w, unsigned *h, size_t *off, size_t *bytes)
+{
+    if (!b || i < 0 || i >= b->n) return HJD_ERR_ARG;
+    const int di = b->dev_index[i];
+    if (di < 0) return b->parse_status[i] ? b->parse_status[i] : HJD_ERR_UNSUPPORTED;
+    if (w) *w = b->img[di].width;
+    if (h) *h = b->img[di].height;
+    if (off) *off = (size_t)b->img[di].out_off;
+    if (bytes) *bytes = b->out_bytes[di];
+    return HJD_OK;
+}
+
+extern "C" void *hjd_batch_out_device_ptr(const hjd_batch *b) { return b ? b->d_out : nullptr; }
+extern "C" size_t hjd_batch_out_bytes(const hjd_batch *b) { return b ? b->out_total : 0; }
+
+extern "C" int hjd_batch_download(hjd_batch *b, int i, uint8_t *dst, size_t cap)
+{
+    if (!b || !dst || i < 0 || i >= b->n) return HJD_ERR_ARG;
+    const int di = b->dev_index[i];
+    if (di < 0) return b->parse_status[i] ? b->parse_status[i] : HJD_ERR_UNSUPPORTED;
+    if (cap < b->out_bytes[di]) return HJD_ERR_ARG;
+    HIPCHK(hipMemcpy(dst, b->d_out + b->img[di].out_off, b->out_bytes[di], hipMemcpyDeviceToHost));
+    return HJD_OK;
+}
+
+extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_t elems)
+{
+    if (!b || !dst || i < 0 || i >= b->n) return HJD_ERR_ARG;
+    const int di = b->dev_index[i];
+    if (di < 0) return HJD_ERR_UNSUPPORTED;
+    const size_t ne = (size_t)b->img[di].nblocks * 64;
+    if (elems < ne) return HJD_ERR_ARG;
+    HIPCHK(hipMemcpy(dst, b->d_coef + b->img[di].coef_off, ne * 2, hipMemcpyDeviceToHost));
+    return HJD_OK;
+}
+
+extern "C" int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *alg, uint64_t *scan)
+{
+    if (!b) return HJD_ERR_ARG;
+    if (pixels) *pixels = b->pixels;
+    if (alg) *alg = b->alg_bytes;
+    if (scan) *scan = b->scan_bytes;
+    return HJD_OK;
+}
+
+extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
+                                     int out_format, uint8_t *const *out, const size_t *out_cap, int *status)
+{
+    if (!d || !out || !out_cap) return HJD_ERR_ARG;
+    std::vector<int> st(n, 0);
+    hjd_batch *b = hjd_batch_prepare(d, n, jpg, jpg_len, out_format, st.data());
+    if (!b) return hjd_last_status();
+    int rc = hjd_batch_run(b, nullptr);
+    if (rc == HJD_OK) rc = hjd_batch_finish(b, nullptr, st.data());
+    for (int i = 0; i < n && rc == HJD_OK; i++) {
+        if (st[i] != HJD_OK) continue;
+        int r = hjd_batch_download(b, i, out[i], out_cap[i]);
+        if (r != HJD_OK) st[i] = r;
+    }
+    if (status) memcpy(status, st.data(), sizeof(int) * n);
+    hjd_batch_destroy(b);
+    return rc;
+}
+
+// ---- single-image entry points (the reference's own API surface) -------------------------------
+
+static std::mutex g_mu;
+static hjd_decoder *g_dec = nullptr;
+
+static hjd_decoder *default_decoder()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_dec) {
+        int dev = 0;
+        const char *e = getenv("HJD_DEVICE");
+        if (e) dev = atoi(e);
+        g_dec = hjd_decoder_create(dev, nullptr);
+    }
+    return g_dec;
+}
+
+static int decode_one_parsed(const hjd_jpeg_data &j, int out_format, std::vector<uint8_t> &out)
+{
+    hjd_decoder *d = default_decoder();
+    if (!d) return HJD_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<hjd_jpeg_data> parsed(1, j);
+    std::vector<int> pst(1, HJD_OK);
+    int st = 0;
+    hjd_batch *b = batch_from_parsed(d, 1, parsed, pst, out_format, &st);
+    if (!b) return hjd_last_status();
+    int rc = st;
+    if (rc == HJD_OK) rc = hjd_batch_run(b, nullptr);
+    if (rc == HJD_OK) {
+        rc = hjd_batch_finish(b, nullptr, &st);
+        if (rc == HJD_OK) rc = st;
+    }
+    if (rc == HJD_OK) {
+        size_t nb = 0;
+        hjd_batch_image_info(b, 0, nullptr, nullptr, nullptr, &nb);
+        out.resize(nb);
+        rc = hjd_batch_download(b, 0, out.data(), nb);
+    }
+    hjd_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int height, unsigned int width,
+                                  unsigned char hFactor, unsigned char vFactor, unsigned char *rgb_out)
+{
+    if (!jdata || !rgb_out || !jdata->stream) return HJD_ERR_ARG;
+    hjd_jpeg_data j = *jdata;
+    j.height = height; // the reference passes these separately (openjpg.cpp:655)
+    j.width = width;
+    j.hfactor = hFactor;
+    j.vfactor = vFactor;
+    if (!width || !height || !(hFactor == 1 || hFactor == 2 || hFactor == 4) ||
+        !(vFactor == 1 || vFactor == 2 || vFactor == 4) || hFactor * vFactor > 4)
+        return HJD_ERR_UNSUPPORTED; // hFactor = 0 is a SIGFPE in the reference (loadjpg.cpp:1153)
+    std::vector<uint8_t> out;
+    int rc = decode_one_parsed(j, HJD_OUT_RGB, out);
+    if (rc == HJD_OK) memcpy(rgb_out, out.data(), out.size());
+    hjd_set_last_status(rc);
+    return rc;
+}
+
+extern "C" int hjd_decode_jpg_file_data(const unsigned char *buf, int sizeBuf, unsigned char **rgbpix,
+                                        unsigned int *width, unsigned int *height)
+{
+    if (!buf || sizeBuf <= 0 || !rgbpix || !width || !height) {
+        hjd_set_last_status(HJD_ERR_ARG);
+        return 0;
+    }
+    hjd_jpeg_data j;
+    int rc = hjd_parse_header(buf, (size_t)sizeBuf, &j);
+    std::vector<uint8_t> out;
+    if (rc == HJD_OK) rc = decode_one_parsed(j, HJD_OUT_RGB, out);
+    hjd_set_last_status(rc);
+    if (rc != HJD_OK) return 0;
+    *rgbpix = (unsigned char *)malloc(out.size());
+    if (!*rgbpix) {
+        hjd_set_last_status(HJD_ERR_INTERNAL);
+        return 0;
+    }
+    memcpy(*rgbpix, out.data(), out.size());
+    *width = j.width;
+    *height = j.height;
+    return 1;
+}
+
+extern "C" int hjd_convert_jpg_file(const char *in, const char *outp)
+{
+    if (!in || !outp) {
+        hjd_set_last_status(HJD_ERR_ARG);
+        return 0;
+    }
+    std::vector<uint8_t> file;
+    if (!hjd_read_file(in, file)) { // openjpg.cpp:603-608
+        hjd_set_last_status(HJD_ERR_IO);
+        fprintf(stderr, "hjd: cannot open jpg file: %s\n", in);
+        return 0;
+    }
+    hjd_jpeg_data j;
+    int rc = hjd_parse_header(file.data(), file.size(), &j);
+    std::vector<uint8_t> bmp;
+    if (rc == HJD_OK) rc = decode_one_parsed(j, HJD_OUT_BMP, bmp);
+    if (rc == HJD_OK && !hjd_write_file(outp, bmp.data(), bmp.size())) rc = HJD_ERR_IO;
+    hjd_set_last_status(rc);
+    if (rc != HJD_OK) {
+        fprintf(stderr, "hjd: %s: %s\n", in, hjd_status_string(rc));
+        return 0;
+    }
+    return 1; // openjpg.cpp:683
+}

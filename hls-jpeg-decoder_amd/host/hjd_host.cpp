@@ -1,0 +1,219 @@
+// hjd_host.cpp — host-side glue on either side of the device path: the JFIF header walk that
+// produces the kernels' inputs (N1) and the BMP/file plumbing that consumes their output (N2).
+// No pixel or entropy arithmetic happens on the host.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hjd.h"
+#include "hjd_internal.h"
+
+static thread_local int t_last_status = HJD_OK;
+void hjd_set_last_status(int s) { t_last_status = s; }
+
+extern "C" int hjd_last_status(void) { return t_last_status; }
+
+extern "C" const char *hjd_status_string(int s)
+{
+    switch (s) {
+    case HJD_OK: return "ok";
+    case HJD_ERR_NOT_JPEG: return "not a JPEG (no SOI / bogus marker)";
+    case HJD_ERR_UNSUPPORTED: return "outside the reference's decodable domain";
+    case HJD_ERR_CORRUPT: return "corrupt or truncated stream";
+    case HJD_ERR_DIRTY_RESTART: return "restart stream outside the clean-resync domain";
+    case HJD_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case HJD_ERR_ARG: return "bad argument";
+    case HJD_ERR_IO: return "file I/O failed";
+    case HJD_ERR_INTERNAL: return "internal / HIP runtime error";
+    default: return "unknown status";
+    }
+}
+
+static inline unsigned be16(const uint8_t *p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+// Header walk with the observable behaviour of JpegParseHeader/ParseJFIF (openjpg.cpp:371-496) on
+// the inputs the reference decodes correctly; everything it would mis-handle (SURVEY.md App. A.2,
+// App. E) is rejected with a status instead.
+extern "C" int hjd_parse_header(const uint8_t *buf, size_t n, hjd_jpeg_data *o)
+{
+    if (!buf || !o) return HJD_ERR_ARG;
+    memset(o, 0, sizeof(*o));
+    if (n < 4 || buf[0] != 0xFF || buf[1] != 0xD8) return HJD_ERR_NOT_JPEG; // openjpg.cpp:481-486
+
+    uint8_t dqt[4][64];
+    bool dqt_def[4] = {false, false, false, false};
+    bool have_sof = false;
+    bool comp_def[4] = {false, false, false, false};
+    unsigned comp_h[4] = {0, 0, 0, 0}, comp_v[4] = {0, 0, 0, 0};
+    size_t pos = 2;
+
+    while (true) { // openjpg.cpp:381-462
+        if (pos >= n) return HJD_ERR_CORRUPT;
+        if (buf[pos++] != 0xFF) return HJD_ERR_NOT_JPEG; // :383-386 "bogus jpeg format"
+        while (pos < n && buf[pos] == 0xFF) pos++;        // :389-392 fill bytes
+        if (pos + 3 > n) return HJD_ERR_CORRUPT;
+        const unsigned marker = buf[pos++];
+        const uint8_t *seg = buf + pos; // the 2-byte length field
+        const size_t left = n - pos;
+        unsigned seglen = be16(seg);
+
+        switch (marker) {
+        case 0xD8:
+        case 0xD9: // :433-439 embedded SOI/EOI: no payload
+            seglen = 0;
+            break;
+        case 0xDB: { // ParseDQT :120-155
+            if (seglen < 2 || seglen > left) return HJD_ERR_CORRUPT;
+            size_t q = 2;
+            while (q < seglen) {
+                if (seglen - q < 65) return HJD_ERR_CORRUPT;
+                const unsigned pq_tq = seg[q];
+                if (pq_tq >> 4) return HJD_ERR_UNSUPPORTED;       // 16-bit tables: reference mis-parses (:136-143)
+                if ((pq_tq & 15) > 3) return HJD_ERR_UNSUPPORTED; // :145-148
+                memcpy(dqt[pq_tq & 15], seg + q + 1, 64);         // kept in zig-zag order (:102-116)
+                dqt_def[pq_tq & 15] = true;
+                q += 65;
+            }
+            break;
+        }
+        case 0xC0: { // ParseSOF :310-367
+            if (seglen < 8 || seglen > left) return HJD_ERR_CORRUPT;
+            if (seg[2] != 8) return HJD_ERR_UNSUPPORTED;
+            o->height = be16(seg + 3);
+            o->width = be16(seg + 5);
+            const unsigned nc = seg[7];
+            if (nc != 3) return HJD_ERR_UNSUPPORTED; // :180-183 "We only support YCbCr"
+            if (seglen < 8 + 3 * nc) return HJD_ERR_CORRUPT;
+            for (unsigned i = 0; i < nc; i++) {
+                const uint8_t *c = seg + 8 + 3 * i;
+                const unsigned id = c[0], tq = c[2];
+                if (id < 1 || id > 3) return HJD_ERR_UNSUPPORTED;       // components are indexed by id (:343)
+                if (tq > 3 || !dqt_def[tq]) return HJD_ERR_UNSUPPORTED; // table is copied at SOF time (:347-350)
+                comp_h[id] = c[1] >> 4; // :345
+                comp_v[id] = c[1] & 15; // :344
+                memcpy(o->qtable[id], dqt[tq], 64);
+                comp_def[id] = true;
+            }
+            have_sof = true;
+            break;
+        }
+        case 0xC4: { // ParseDHT :234-305
+            if (seglen < 2 || seglen > left) return HJD_ERR_CORRUPT;
+            size_t q = 2;
+            while (q < seglen) {
+                if (seglen - q < 17) return HJD_ERR_CORRUPT;
+                const unsigned tc_th = seg[q];
+                if ((tc_th & 15) > 3) return HJD_ERR_UNSUPPORTED; // :273-276
+                hjd_huff_spec *h = (tc_th & 0xF0) ? &o->htac[tc_th & 15] : &o->htdc[tc_th & 15];
+                unsigned total = 0;
+                h->bits[0] = 0;
+                for (int k = 1; k <= 16; k++) {
+                    h->bits[k] = seg[q + k];
+                    total += h->bits[k];
+                }
+                if (total > 255) return HJD_ERR_UNSUPPORTED; // uint8_t scan index never terminates (loadjpg.cpp:350-355)
+                if (seglen - q < 17 + total) return HJD_ERR_CORRUPT;
+                memset(h->vals, 0, sizeof(h->vals));
+                memcpy(h->vals, seg + q + 17, total);
+                // canonical code assignment must stay inside each length (GenHuffCodes :48-66)
+                unsigned code = 0;
+                for (int k = 1; k <= 16; k++) {
+                    code += h->bits[k];
+                    if (code > (1u << k)) return HJD_ERR_CORRUPT;
+                    code <<= 1;
+                }
+                if (!(tc_th & 0xF0)) {
+                    if (h->bits[16]) return HJD_ERR_UNSUPPORTED; // DC search stops at 15 bits (loadjpg.cpp:562)
+                    for (unsigned k = 0; k < total; k++)
+                        if (h->vals[k] > 15) return HJD_ERR_UNSUPPORTED; // reader holds at most 2 new bytes (:468-482)
+                }
+                h->defined = 1;
+                q += 17 + total;
+            }
+            break;
+        }
+        case 0xDD: // :441-446 — the reference stores the LENGTH field and only tests it > 0
+            if (seglen > left) return HJD_ERR_CORRUPT;
+            o->restart_interval = (int)seglen;
+            o->restart_mcus = seglen >= 4 ? be16(seg + 2) : 0;
+            break;
+        case 0xDA: { // ParseSOS :160-229
+            if (!have_sof) return HJD_ERR_UNSUPPORTED; // SOF1/SOF2/...: "Unknown marker", then SIGFPE (loadjpg.cpp:1153)
+            if (left < 3) return HJD_ERR_CORRUPT;
+            const unsigned ns = seg[2];
+            if (ns != 3) return HJD_ERR_UNSUPPORTED;
+            if (left < 3 + 2 * ns + 3) return HJD_ERR_CORRUPT;
+            for (unsigned i = 0; i < ns; i++) {
+                const unsigned id = seg[3 + 2 * i], sel = seg[4 + 2 * i];
+                if (id != i + 1) return HJD_ERR_UNSUPPORTED; // block order is fixed Y,Cb,Cr (loadjpg.cpp:945-997)
+                if ((sel & 15) > 3 || (sel >> 4) > 3) return HJD_ERR_UNSUPPORTED;
+                o->ac_table_index[id] = sel & 15; // :212
+                o->dc_table_index[id] = sel >> 4; // :213
+                if (!o->htac[sel & 15].defined || !o->htdc[sel >> 4].defined) return HJD_ERR_UNSUPPORTED;
+            }
+            const size_t first = pos + 3 + 2 * ns + 3; // :186-190 and the "+3" of :222
+            o->stream = buf + first;
+            o->stream_len = n - first;
+            o->header_bytes = first;
+            goto walked;
+        }
+        default: // APPn, COM, unknown: skipped by length (:448-458)
+            if (seglen > left) return HJD_ERR_CORRUPT;
+            break;
+        }
+        pos += seglen; // :461
+    }
+walked:
+    if (!comp_def[1] || !comp_def[2] || !comp_def[3]) return HJD_ERR_UNSUPPORTED;
+    // one Cb + one Cr block per MCU (loadjpg.cpp:974-996); m_Y holds four luma blocks (loadjpg.h:165);
+    // the chroma index math of loadjpg.cpp:912 is exact only for factors 1, 2, 4
+    if (comp_h[2] != 1 || comp_v[2] != 1 || comp_h[3] != 1 || comp_v[3] != 1) return HJD_ERR_UNSUPPORTED;
+    const unsigned hf = comp_h[1], vf = comp_v[1];
+    if (!(hf == 1 || hf == 2 || hf == 4) || !(vf == 1 || vf == 2 || vf == 4) || hf * vf > 4) return HJD_ERR_UNSUPPORTED;
+    if (!o->width || !o->height) return HJD_ERR_UNSUPPORTED;
+    if (o->stream_len == 0) return HJD_ERR_CORRUPT;
+    o->hfactor = (uint8_t)hf;
+    o->vfactor = (uint8_t)vf;
+    return HJD_OK;
+}
+
+// ---- sizes / BMP (WriteBMP24, openjpg.cpp:504-570) ------------------------------------------------
+
+extern "C" size_t hjd_rgb_bytes(unsigned w, unsigned h) { return (size_t)w * h * 3; }
+
+extern "C" size_t hjd_bmp_bytes(unsigned w, unsigned h)
+{
+    const unsigned pad = (4 - (w * 3) % 4) % 4; // :534-535
+    return (size_t)w * h * 3 + (size_t)h * pad + 54; // :541
+}
+
+extern "C" void hjd_free(void *p) { free(p); }
+
+bool hjd_read_file(const char *path, std::vector<uint8_t> &out)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (sz < 0) {
+        fclose(fp);
+        return false;
+    }
+    out.resize((size_t)sz);
+    bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, fp) == (size_t)sz;
+    fclose(fp);
+    return ok;
+}
+
+bool hjd_write_file(const char *path, const uint8_t *data, size_t n)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return false;
+    bool ok = fwrite(data, 1, n, fp) == n;
+    ok = (fclose(fp) == 0) && ok;
+    return ok;
+}

@@ -1,0 +1,166 @@
+/*
+ * hjd.h — C ABI of the MI355X-native baseline-JPEG decode path.
+ *
+ * This is the drop-in boundary for the hot path of harutel/hls-jpeg-decoder
+ * (everything reachable from JpegDecodeHW, reference src/loadjpg.cpp:1134-1190):
+ * Huffman VLC decode, dequantise, 8x8 IDCT, chroma upsample, YCbCr->RGB, run as
+ * hand-written HIP kernels for gfx950.  Plain pointers and sizes only.
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * the reference's src/).  Results are byte-identical to the reference's CPU
+ * decoder inside its parity domain; outside it the calls
+ * return an error status instead of emulating the reference's undefined
+ * behaviour.  There is NO CPU fallback: without a usable HIP device every
+ * decode call fails with HJD_ERR_NO_DEVICE.
+ */
+#ifndef HJD_H
+#define HJD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (per call and per image) -------------------------------- */
+typedef enum hjd_status {
+    HJD_OK = 0,
+    HJD_ERR_NOT_JPEG = 1,       /* openjpg.cpp:481-486 / :383-386: no SOI, or a marker without 0xFF */
+    HJD_ERR_UNSUPPORTED = 2,    /* valid JPEG outside the reference's domain (progressive, grey, 16-bit DQT, ...) */
+    HJD_ERR_CORRUPT = 3,        /* truncated segment, invalid Huffman code or coefficient overrun in the scan */
+    HJD_ERR_DIRTY_RESTART = 4,  /* restart stream outside the clean-resync domain */
+    HJD_ERR_NO_DEVICE = 5,      /* no usable HIP device / kernel image: the product path has no CPU fallback */
+    HJD_ERR_ARG = 6,            /* NULL pointer, size too small, bad enum */
+    HJD_ERR_IO = 7,             /* file open/read/write failed */
+    HJD_ERR_INTERNAL = 8        /* HIP runtime error or synchronisation did not converge */
+} hjd_status;
+
+const char *hjd_status_string(int status);
+/* status of the last failing call on this thread (for the 1/0-returning entry points) */
+int hjd_last_status(void);
+
+/* ---- (1) file in, BMP file out -------------------------------------------- *
+ * Replaces: int ConvertJpgFile(char*, char*)   openjpg.h:23, openjpg.cpp:593-684.
+ * Same convention: returns 1 on success, 0 on failure.  The BMP bytes follow
+ * WriteBMP24 (openjpg.cpp:504-570): 54-byte header, bottom-up rows, B,G,R order,
+ * rows padded to 4 bytes (pad bytes are written as zero; the reference leaves pad
+ * bytes 2 and 3 undefined).                                                     */
+int hjd_convert_jpg_file(const char *szJpgFileInName, const char *szBmpFileOutName);
+
+/* ---- (2) memory in, RGB out ------------------------------------------------ *
+ * Replaces: int DecodeJpgFileData(const unsigned char*, int, unsigned char**,
+ *           unsigned int*, unsigned int*)   openjpg.h:25-27 / loadjpg.h:185-187
+ * (declared, never defined by the reference; its body is inlined at
+ * openjpg.cpp:623-655).  Callee allocates *rgbpix (top-down, R,G,B, 3*W*H
+ * bytes); release it with hjd_free() — the reference's "delete[] rgbpix" cannot
+ * cross a C ABI.  Returns 1 on success, 0 on failure.                          */
+int hjd_decode_jpg_file_data(const unsigned char *buf, int sizeBuf, unsigned char **rgbpix,
+                             unsigned int *width, unsigned int *height);
+void hjd_free(void *p);
+
+/* ---- (3) the HW/SW cut: already-parsed tables + scan bytes -> RGB ---------- *
+ * Replaces: int JpegDecodeHW(stJpegData*, unsigned h, unsigned w, uchar hFactor,
+ *           uchar vFactor)   loadjpg.h:180, loadjpg.cpp:1134-1190.
+ * hjd_jpeg_data carries what JpegDecodeHW reads from stJpegData (loadjpg.h:157-171)
+ * with pointer/length fields instead of fixed-capacity arrays.                  */
+typedef struct hjd_huff_spec {
+    uint8_t defined;
+    uint8_t bits[17];   /* bits[1..16] = number of codes of each length (DHT payload, openjpg.cpp:261-267) */
+    uint8_t vals[256];  /* symbol values in code order (openjpg.cpp:282-295) */
+} hjd_huff_spec;
+
+typedef struct hjd_jpeg_data {
+    /* stComponent::m_qTable for component ids 1..3, raw DQT (zig-zag) order (openjpg.cpp:347-350).
+     * Index 0 unused.  The Cb-uses-Cr's-table quirk (loadjpg.cpp:984) is applied by the decoder. */
+    uint8_t qtable[4][64];
+    uint8_t dc_table_index[4]; /* stComponent::dcTable_index per component id (openjpg.cpp:213) */
+    uint8_t ac_table_index[4]; /* stComponent::acTable_index (openjpg.cpp:212) */
+    hjd_huff_spec htdc[4];     /* stHuffmanData::m_HTDC */
+    hjd_huff_spec htac[4];     /* stHuffmanData::m_HTAC */
+    const uint8_t *stream;     /* stHuffmanData::m_stream: first entropy-coded byte (openjpg.cpp:220-223) */
+    size_t stream_len;
+    int restart_interval;      /* stHuffmanData::m_restart_interval: only tested ">0" (loadjpg.cpp:535,631) */
+    unsigned restart_mcus;     /* DRI payload Ri (the reference never reads it; needed to find intervals) */
+    /* frame header (stImageInfo, openjpg.h:11-17) */
+    unsigned width, height;
+    uint8_t hfactor, vfactor;  /* m_hFactor[cY], m_vFactor[cY] */
+    size_t header_bytes;
+} hjd_jpeg_data;
+
+/* Host header walk.  Replaces JpegParseHeader / ParseJFIF (openjpg.cpp:371-496).
+ * Fills `out`; out->stream points INTO buf. */
+int hjd_parse_header(const uint8_t *buf, size_t size, hjd_jpeg_data *out);
+
+/* Same argument order as the reference: (jdata, height, width, hFactor, vFactor).
+ * rgb_out: host buffer of 3*width*height bytes (stJpegData::m_rgb).  Returns an hjd_status
+ * (the reference returns 0 always). */
+int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int jpeg_img_height, unsigned int jpeg_img_width,
+                       unsigned char hFactor, unsigned char vFactor, unsigned char *rgb_out);
+
+/* ---- (4) batch API (new; the reference decodes one image per process) ------ */
+typedef struct hjd_decoder hjd_decoder; /* one per (process, device): kernels, LUT cache, workspace */
+typedef struct hjd_batch hjd_batch;     /* N images resident in HBM, ready to decode */
+
+typedef enum hjd_out_format {
+    HJD_OUT_RGB = 0, /* stJpegData::m_rgb layout: top-down, R,G,B, stride 3*W */
+    HJD_OUT_BMP = 1  /* WriteBMP24 file image (openjpg.cpp:504-570) */
+} hjd_out_format;
+
+typedef struct hjd_options {
+    int subseq_bits;     /* entropy-decode subsequence size in bits (multiple of 32, 64..4096); 0 = default */
+    int sync_launches;   /* speculative synchronisation launches before verification; 0 = default */
+    int reserved[6];
+} hjd_options;
+
+hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);
+void hjd_decoder_destroy(hjd_decoder *d);
+int hjd_device_count(void);
+
+/* Parse N JPEG files (host pointers), upload scans + tables to HBM, size the workspace.
+ * status[i] receives the per-image parse status; images that fail to parse are skipped
+ * by run/download.  Returns NULL only on argument / device errors. */
+hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
+                             int out_format, int *status);
+void hjd_batch_destroy(hjd_batch *b);
+
+/* Enqueue the whole decode (all kernels) on `hip_stream` (a hipStream_t, may be NULL = default
+ * stream).  Asynchronous; inputs and outputs stay in HBM. */
+int hjd_batch_run(hjd_batch *b, void *hip_stream);
+/* Wait for the stream, verify on-device convergence flags, fill status[i] (may be NULL). */
+int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status);
+
+/* Per-image output location inside the batch's device slab. */
+int hjd_batch_image_info(const hjd_batch *b, int i, unsigned *width, unsigned *height, size_t *out_offset,
+                         size_t *out_bytes);
+void *hjd_batch_out_device_ptr(const hjd_batch *b);
+size_t hjd_batch_out_bytes(const hjd_batch *b);
+/* Copy image i's output (RGB or BMP bytes) to host memory. */
+int hjd_batch_download(hjd_batch *b, int i, uint8_t *dst, size_t dst_cap);
+
+/* Algorithmic bytes of the batch: sum over decodable images of
+ * scan_bytes + header_bytes + 3*W*H; and total pixels. */
+int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *algorithmic_bytes, uint64_t *scan_bytes);
+
+/* Per-kernel device time of ONE run measured with hipEvents on `hip_stream` (diagnostics /
+ * bench.py roofline).  names[k] are static strings; returns the number of stages written. */
+#define HJD_MAX_STAGES 16
+int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const char **stage_names, int cap);
+
+/* Convenience: decode N host JPEGs to N caller-provided host buffers (RGB or BMP). */
+int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
+                          int out_format, uint8_t *const *out, const size_t *out_cap, int *status);
+
+/* Size helpers (WriteBMP24 arithmetic, openjpg.cpp:534-541). */
+size_t hjd_bmp_bytes(unsigned width, unsigned height);
+size_t hjd_rgb_bytes(unsigned width, unsigned height);
+
+/* Test hooks: run single stages on device buffers so each kernel can be checked against the
+ * oracle in isolation.  coefs: nblocks*64 int16, zig-zag order, DC predictor applied (the
+ * DCT[] array after ProcessHuffmanBlock, loadjpg.cpp:499-863). */
+int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_t dst_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJD_H */
