@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s JPEG->RGB on a synthetic 3840x2160 4:2:0 q85 baseline batch (BASELINE.json).
+
+One "step" = one pass of the whole hot path (unstuff, Huffman synchronise + decode, dequantise,
+IDCT, upsample, YCbCr->RGB) over one batch of JPEGs that is already resident in HBM; outputs
+stay in HBM.  One process per GPU; images are independent, so ranks share nothing on the data
+path (weak scaling: the per-GPU batch is fixed).  torch is used for the process group (barrier
+and the max-over-ranks of the elapsed time) and for the HIP stream handle only.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(jpgs, w, h):
+    """The reference's CPU path on this box's host cores, bounded sample.  kind 'reference' = the
+    compiled reference itself (oracle/_ref/ref_big, built in the build container from the reference
+    sources, single-threaded like the reference); 'port' = our C restatement (oracle/)."""
+    import hjdtools as T
+    ncores = os.cpu_count()
+    exe = T.ref_binary(big=True)
+    sample = jpgs[:2]
+    with tempfile.TemporaryDirectory() as td:
+        if exe:
+            t0 = time.time()
+            for i, j in enumerate(sample):
+                jp, bp = os.path.join(td, "%d.jpg" % i), os.path.join(td, "%d.bmp" % i)
+                open(jp, "wb").write(j)
+                T.ref_convert(jp, bp, big=True, timeout=600)
+            dt = time.time() - t0
+            kind = "reference"
+        else:
+            sample = jpgs[:8]
+            t0 = time.time()
+            for j in sample:
+                rc, rgb, _, _, _ = T.oracle_decode(j)
+                T.oracle_bmp(rgb)
+            dt = time.time() - t0
+            kind = "port"
+    return {"value": round(len(sample) * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": "%d x %dx%d 4:2:0 q85 JPEG -> BMP, single thread (host has %d cores), incl. file I/O"
+                      % (len(sample), w, h, ncores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--quality", type=int, default=85)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images replicated to fill the batch")
+    ap.add_argument("--subseq-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import hjdtools as T
+    hjd = importlib.import_module("hls-jpeg-decoder_amd")
+
+    W, H = args.width, args.height
+    distinct = [T.synth_jpeg(W, H, 1000 + 17 * rank + k, args.quality, 2, 2) for k in range(max(1, args.distinct))]
+    jpgs = [distinct[i % len(distinct)] for i in range(args.batch)]
+
+    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits)
+    batch = dec.prepare(jpgs, hjd.OUT_RGB)  # parse + H2D: inputs are resident in HBM from here on
+    assert all(s == 0 for s in batch.parse_status), batch.parse_status
+    pixels, alg_bytes, scan_bytes = batch.totals()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(stream)
+    barrier()
+    st = batch.finish(stream)
+    assert all(s == 0 for s in st), st
+
+    batch.enable_timing(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    st = batch.finish(stream)
+    assert all(s == 0 for s in st), st
+    stages, runs = batch.collect_timing()
+
+    # parity of what was just timed: compare images of the batch with the CPU oracle (checker only)
+    parity = "ok"
+    for i in sorted(set([0, len(jpgs) - 1])):
+        rc, orgb, _, _, _ = T.oracle_decode(jpgs[i])
+        got = batch.download(i)
+        if rc != 0 or got.shape != orgb.shape or not (got == orgb).all():
+            parity = "MISMATCH image %d" % i
+    if parity != "ok":
+        raise SystemExit("bench: output differs from the oracle: " + parity)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(pixels)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_pixels = float(tot.item())
+    else:
+        total_pixels = float(pixels)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = total_pixels * args.steps / dt / 1e6
+        stage_ms = {n: round(ms, 4) for n, ms in stages}
+        dom = max(stages, key=lambda x: x[1]) if stages else ("none", 0.0)
+        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "scan": "k_scan",
+                     "huff_write": "k_write", "idct_color": "k_idct_color", "coef_clear": "hipMemsetAsync",
+                     "reset": "hipMemsetAsync"}
+        achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(dom[0])
+                if ent and ent.get("batch") == args.batch and ent.get("width") == W and ent.get("height") == H:
+                    traffic = ent["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)",
+            "value": round(value, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 entropy/pixel bytes, int16 coefficients, f32 IDCT+colour (reference arithmetic)",
+            "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU, resident in HBM, "
+                                   "RGB out to HBM" % (args.batch, W, H, args.quality),
+                       "images_per_gpu": args.batch, "distinct_images": len(distinct), "width": W, "height": H,
+                       "scan_bytes_per_image": scan_bytes // max(1, args.batch),
+                       "algorithmic_bytes_per_image": alg_bytes // max(1, args.batch), "parallelism": "images sharded, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms": stage_ms,
+            "timed_runs": runs,
+            "parity": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(jpgs, W, H)
+        print(json.dumps(out), flush=True)
+
+    batch.close()
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
+    "hjd_batch_run_timed", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
 ]
 
 
@@ -103,6 +103,11 @@ def lib():
     L.hjd_batch_run_timed.restype = ctypes.c_int
     L.hjd_batch_run_timed.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p),
                                       ctypes.c_int]
+    L.hjd_batch_enable_timing.restype = ctypes.c_int
+    L.hjd_batch_enable_timing.argtypes = [vp, ctypes.c_int]
+    L.hjd_batch_collect_timing.restype = ctypes.c_int
+    L.hjd_batch_collect_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p),
+                                           ctypes.c_int, ip]
     L.hjd_decode_batch_host.restype = ctypes.c_int
     L.hjd_bmp_bytes.restype = sz
     L.hjd_bmp_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint]
@@ -196,6 +201,21 @@ class Batch:
         if n < 0:
             raise RuntimeError("hjd_batch_run_timed failed")
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def enable_timing(self, max_runs):
+        rc = lib().hjd_batch_enable_timing(self._h, max_runs)
+        if rc:
+            raise RuntimeError("hjd_batch_enable_timing: %s" % status_string(rc))
+
+    def collect_timing(self):
+        """[(stage, average ms)] over the runs recorded since enable_timing / the last collect."""
+        ms = (ctypes.c_float * MAX_STAGES)()
+        names = (ctypes.c_char_p * MAX_STAGES)()
+        runs = ctypes.c_int()
+        n = lib().hjd_batch_collect_timing(self._h, ms, names, MAX_STAGES, ctypes.byref(runs))
+        if n < 0:
+            raise RuntimeError("hjd_batch_collect_timing failed")
+        return [(names[i].decode(), float(ms[i])) for i in range(n)], runs.value
 
     def info(self, i):
         w, h = ctypes.c_uint(), ctypes.c_uint()

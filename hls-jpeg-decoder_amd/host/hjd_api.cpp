@@ -58,6 +58,11 @@ struct hjd_batch {
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
+    // optional per-run stage timing (hjd_batch_enable_timing): one event set per recorded run
+    std::vector<std::vector<hipEvent_t>> tev;
+    std::vector<int> tev_n;
+    const char *tev_names[HJD_MAX_STAGES + 1] = {};
+    int tev_cap = 0;
 };
 
 // ---- Huffman table construction (GenHuffCodes / BuildHuffmanTable, openjpg.cpp:48-98) ----------
@@ -162,6 +167,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_coef);
     if (b->have_events)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
+    for (auto &v : b->tev)
+        for (auto &e : v) (void)hipEventDestroy(e);
 }
 
 extern "C" void hjd_batch_destroy(hjd_batch *b)
@@ -343,8 +350,10 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
 }
 
 // the kernel sequence; ev != nullptr records an event before each stage and one after the last
-static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nstage, const char **names)
+static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nstage, const char **names,
+                         hipEvent_t *evs = nullptr)
 {
+    if (!evs) evs = b->ev;
     if (!b->nimg) {
         if (nstage) *nstage = 0;
         return HJD_OK;
@@ -355,7 +364,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         if (names) {
             if (k < HJD_MAX_STAGES) {
                 names[k] = name;
-                if (hipEventRecord(b->ev[k], s) != hipSuccess) return HJD_ERR_INTERNAL;
+                if (hipEventRecord(evs[k], s) != hipSuccess) return HJD_ERR_INTERNAL;
             }
             k++;
         }
@@ -390,7 +399,54 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
 extern "C" int hjd_batch_run(hjd_batch *b, void *hip_stream)
 {
     if (!b) return HJD_ERR_ARG;
+    if ((int)b->tev_n.size() < b->tev_cap) { // timing enabled and room left: record this run's stage events
+        const int r = (int)b->tev_n.size();
+        int ns = 0;
+        int rc = batch_enqueue(b, (hipStream_t)hip_stream, false, &ns, b->tev_names, b->tev[r].data());
+        b->tev_n.push_back(rc == HJD_OK ? ns : 0);
+        return rc;
+    }
     return batch_enqueue(b, (hipStream_t)hip_stream, false, nullptr, nullptr);
+}
+
+extern "C" int hjd_batch_enable_timing(hjd_batch *b, int max_runs)
+{
+    if (!b || max_runs < 0 || max_runs > 4096) return HJD_ERR_ARG;
+    for (auto &v : b->tev)
+        for (auto &e : v) (void)hipEventDestroy(e);
+    b->tev.clear();
+    b->tev_n.clear();
+    b->tev_cap = 0;
+    b->tev.resize(max_runs);
+    for (auto &v : b->tev) {
+        v.resize(HJD_MAX_STAGES + 1);
+        for (auto &e : v) HIPCHK(hipEventCreate(&e));
+    }
+    b->tev_cap = max_runs;
+    return HJD_OK;
+}
+
+extern "C" int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **stage_names, int cap, int *runs)
+{
+    if (!b || !stage_ms_avg || !stage_names) return -1;
+    int nout = 0, nr = 0;
+    for (size_t r = 0; r < b->tev_n.size(); r++) {
+        const int ns = b->tev_n[r];
+        if (ns < 2) continue;
+        nout = ns - 1 < cap ? ns - 1 : cap;
+        for (int k = 0; k < nout; k++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, b->tev[r][k], b->tev[r][k + 1]) != hipSuccess) return -1;
+            if (nr == 0) stage_ms_avg[k] = 0;
+            stage_ms_avg[k] += ms;
+            stage_names[k] = b->tev_names[k];
+        }
+        nr++;
+    }
+    for (int k = 0; k < nout && nr; k++) stage_ms_avg[k] /= (float)nr;
+    if (runs) *runs = nr;
+    b->tev_n.clear(); // ready to record again
+    return nout;
 }
 
 extern "C" int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const char **stage_names, int cap)

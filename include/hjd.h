@@ -147,6 +147,12 @@ int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *algorithmic
 #define HJD_MAX_STAGES 16
 int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const char **stage_names, int cap);
 
+/* Stage timing inside the normal run path: after hjd_batch_enable_timing(b, R) the next R calls of
+ * hjd_batch_run record a hipEvent before every stage on the run's stream (no extra synchronisation);
+ * hjd_batch_collect_timing (call it after the stream has been synchronised) averages them. */
+int hjd_batch_enable_timing(hjd_batch *b, int max_runs);
+int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **stage_names, int cap, int *runs);
+
 /* Convenience: decode N host JPEGs to N caller-provided host buffers (RGB or BMP). */
 int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
                           int out_format, uint8_t *const *out, const size_t *out_cap, int *status);

@@ -1,0 +1,90 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/hjd.h declares,
+parses headers like the oracle does, and refuses to decode without a HIP device (no fallback)."""
+import importlib
+import os
+import re
+
+import pytest
+
+import hjdtools as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hjd():
+    m = importlib.import_module("hls-jpeg-decoder_amd")
+    if not os.path.exists(m.LIB_PATH):
+        import subprocess
+        subprocess.run(["make", "-s", "lib"], cwd=ROOT, check=True)
+    return m
+
+
+def test_exports_every_declared_symbol(hjd):
+    hdr = open(os.path.join(ROOT, "include", "hjd.h")).read()
+    declared = set(re.findall(r"\b(hjd_[a-z_0-9]+)\s*\(", hdr))
+    L = hjd.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(hjd.EXPORTS), declared ^ set(hjd.EXPORTS)
+
+
+def test_header_parse_matches_oracle(hjd, golden):
+    d, man = golden
+    for name, ent in sorted(man.items()):
+        data = open(os.path.join(d, name), "rb").read()
+        st, jd = hjd.parse_header(data)
+        if ent["status"] == "unsupported":
+            assert st == hjd.HJD_ERR_UNSUPPORTED, name
+            continue
+        assert st == 0, name
+        assert (jd.width, jd.height, jd.hfactor, jd.vfactor) == (ent["width"], ent["height"], ent["hf"], ent["vf"]), name
+        assert bool(jd.restart_interval) == (ent["restart"] != "none"), name
+        assert jd.header_bytes + jd.stream_len == len(data), name
+
+
+def test_parse_rejects(hjd, golden):
+    d, _ = golden
+    lenna = open(os.path.join(d, "Lenna.jpg"), "rb").read()
+    assert hjd.parse_header(b"nope")[0] == hjd.HJD_ERR_NOT_JPEG
+    assert hjd.parse_header(lenna[:100])[0] == hjd.HJD_ERR_CORRUPT
+    assert hjd.parse_header(b"\xff\xd8\x00\x00\x00")[0] == hjd.HJD_ERR_NOT_JPEG
+    # 16-bit DQT
+    i = lenna.index(b"\xff\xdb")
+    bad = bytearray(lenna)
+    bad[i + 4] |= 0x10
+    assert hjd.parse_header(bytes(bad))[0] == hjd.HJD_ERR_UNSUPPORTED
+
+
+def test_sizes(hjd):
+    L = hjd.lib()
+    assert L.hjd_bmp_bytes(512, 512) == 786486
+    assert L.hjd_bmp_bytes(250, 187) == 54 + 187 * 752
+    assert L.hjd_rgb_bytes(3840, 2160) == 24883200
+
+
+def test_no_device_means_failure_not_fallback(hjd, tmp_path, golden):
+    """Without a GPU the product must fail loudly (this test only asserts that when no device exists)."""
+    if hjd.lib().hjd_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(RuntimeError):
+        hjd.Decoder(0)
+    d, _ = golden
+    out = tmp_path / "o.bmp"
+    assert hjd.convert_jpg_file(os.path.join(d, "Lenna.jpg"), str(out)) == 0
+    assert hjd.lib().hjd_last_status() == hjd.HJD_ERR_NO_DEVICE
+    assert not out.exists()
+
+
+def test_product_does_not_reference_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may mention it."""
+    bad = []
+    for base in ("hls-jpeg-decoder_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".so", ".o")) or "__pycache__" in dp or "/bin" in dp:
+                    continue
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if "hjd_oracle" in txt or "oracle/" in txt or "hjo_" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
