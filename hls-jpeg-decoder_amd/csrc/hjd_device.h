@@ -65,7 +65,10 @@ struct HjdImageState {
     uint32_t ustream_len;   // unstuffed bytes
     uint32_t flags;         // HJD_FLAG_*
     uint32_t total_blocks;  // blocks completed over all subsequences
-    uint32_t pad;
+    uint32_t sync_iters;    // diagnostics: sum over workgroups and launches of refinement iterations
+    uint32_t sync_decodes;  // diagnostics: subsequence decodes executed by the synchronisation launches
+    uint32_t sync_iters_max;
+    uint32_t pad[2];
 };
 #define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)

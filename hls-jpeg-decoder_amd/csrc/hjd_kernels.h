@@ -17,7 +17,8 @@ struct HjdParams {
     int16_t *coef;             // dense coefficients
     uint8_t *out;              // RGB / BMP bytes
     int nimg;
-    uint32_t subseq_bits;
+    uint32_t subseq_bits;      // power of two, 64..2048
+    uint32_t log2_words;       // log2(subseq_bits / 32)
 };
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);

@@ -172,23 +172,52 @@ __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_l
     for (uint32_t k = threadIdx.x; k < nslow; k += blockDim.x) sd[k] = ss[k];
 }
 
-// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration, no divergence
-// except the long-code slow path and the word reload.
+// The workgroup's span of the bit string (HJD_SYNC_WG subsequences + a few words of overshoot)
+// is staged once into LDS with coalesced 16-byte loads; lanes then read their words from LDS.
+// Row r (one subsequence = 2^lw words) is padded by one word so that lanes reading the same
+// column of their rows hit different banks.
+struct StreamLds {
+    const uint32_t *s; // staged words
+    uint32_t w0;       // image-relative index of the first staged word
+    uint32_t lw;       // log2(words per subsequence)
+    __device__ __forceinline__ uint32_t word(uint32_t widx) const
+    {
+        const uint32_t r = widx - w0;
+        return s[r + (r >> lw)];
+    }
+};
+
+__device__ __forceinline__ void stage_stream(const uint32_t *__restrict__ w, uint32_t w0, uint32_t lw, uint32_t *s_stream)
+{
+    const uint32_t nwords = ((uint32_t)HJD_SYNC_WG << lw) + 8; // span + overshoot (31 bits + 2 prefetched words)
+    const uint4 *src = reinterpret_cast<const uint4 *>(w + w0);
+    for (uint32_t k = threadIdx.x; k < nwords / 4; k += blockDim.x) {
+        const uint4 v = src[k];
+        const uint32_t i0 = 4 * k;
+        s_stream[i0 + (i0 >> lw)] = v.x;
+        s_stream[i0 + 1 + ((i0 + 1) >> lw)] = v.y;
+        s_stream[i0 + 2 + ((i0 + 2) >> lw)] = v.z;
+        s_stream[i0 + 3 + ((i0 + 3) >> lw)] = v.w;
+    }
+}
+
+// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration; the only
+// divergent paths are the long-code search and (WRITE) the stores.
 //   WRITE = false: nblk counts blocks completed, dc0..2 sum the DC differences   (synchronisation)
 //   WRITE = true : nblk is the absolute block index, dc0..2 the running predictors; coefficients
 //                  are stored in zig-zag order (the DCT[] array of loadjpg.cpp:499-863)
 template <bool WRITE>
-__device__ __forceinline__ void decode_span(const uint32_t *__restrict__ w, const uint16_t *s_lut,
-                                            const SlowTab *s_slow, uint32_t nby, uint32_t nb, uint32_t &p,
-                                            uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk, int &dc0,
-                                            int &dc1, int &dc2, int16_t *__restrict__ coef, uint32_t nblocks,
-                                            uint32_t &flags)
+__device__ __forceinline__ void decode_span(const StreamLds &sl, const uint16_t *s_lut, const SlowTab *s_slow,
+                                            uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                            uint32_t end, uint32_t &nblk, int &dc0, int &dc1, int &dc2,
+                                            int16_t *__restrict__ coef, uint32_t nblocks, uint32_t &flags)
 {
     uint32_t wi = p >> 5, o = p & 31;
-    uint32_t hi = w[wi], lo = w[wi + 1], nx = w[wi + 2];
-    wi += 3;
+    uint32_t hi = sl.word(wi), lo = sl.word(wi + 1);
+    wi += 2;
     uint32_t comp = m < nby ? 0u : m - nby + 1u;
     while (p < end && (!WRITE || nblk < nblocks)) {
+        const uint32_t nxt = sl.word(wi); // next word, fetched alongside the table lookup
         const uint32_t win = __funnelshift_l(lo, hi, o);
         const uint32_t slot = comp * 2u + (z != 0u ? 1u : 0u);
         const uint32_t e = s_lut[slot * HJD_LUT_SIZE + (win >> (32 - HJD_LUT_BITS))];
@@ -220,17 +249,17 @@ __device__ __forceinline__ void decode_span(const uint32_t *__restrict__ w, cons
         // value bits + DetermineSign (loadjpg.cpp:396-409)
         const uint32_t vb = ((win << len) >> 1) >> (31u - s);
         const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
-        if (z == 0u) { // DC: loadjpg.cpp:619-667
-            dc0 += comp == 0u ? val : 0;
-            dc1 += comp == 1u ? val : 0;
-            dc2 += comp == 2u ? val : 0;
-            if (WRITE) coef[(size_t)nblk * 64] = (int16_t)(comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2));
-        } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
-            const uint32_t zw = z + adv - 1u;
-            if (zw <= 63u) {
-                if (WRITE) coef[(size_t)nblk * 64 + zw] = (int16_t)val;
-            } else if (WRITE) {
-                flags |= HJD_FLAG_OVERRUN;
+        const bool isdc = z == 0u;
+        const int dval = isdc ? val : 0; // DC: loadjpg.cpp:619-667
+        dc0 += comp == 0u ? dval : 0;
+        dc1 += comp == 1u ? dval : 0;
+        dc2 += comp == 2u ? dval : 0;
+        if (WRITE) {
+            const uint32_t zw = isdc ? 0u : z + adv - 1u; // AC run/size: loadjpg.cpp:776-808
+            const int16_t cv = isdc ? (int16_t)(comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2)) : (int16_t)val;
+            if (isdc || s != 0u) {
+                if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = cv;
+                else flags |= HJD_FLAG_OVERRUN;
             }
         }
         z += adv;
@@ -244,12 +273,11 @@ __device__ __forceinline__ void decode_span(const uint32_t *__restrict__ w, cons
         const uint32_t tot = len + s;
         p += tot;
         o += tot;
-        if (o >= 32u) {
-            o -= 32u;
-            hi = lo;
-            lo = nx;
-            nx = w[wi++];
-        }
+        const bool roll = o >= 32u;
+        hi = roll ? lo : hi;
+        lo = roll ? nxt : lo;
+        wi += roll ? 1u : 0u;
+        o &= 31u;
     }
 }
 
@@ -260,6 +288,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[HJD_SLOTS * HJD_LUT_SIZE];
     __shared__ __attribute__((aligned(16))) SlowTab s_slow;
     __shared__ uint32_t s_ep[HJD_SYNC_WG], s_ezm[HJD_SYNC_WG];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stream[];
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.syncwg0; });
@@ -267,6 +296,9 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
     load_tables(&P.tabs[im.tabset], s_lut, &s_slow);
 
     const uint32_t S = P.subseq_bits;
+    const uint32_t lw = P.log2_words;
+    const StreamLds sl = {s_stream, ((blockIdx.x - im.syncwg0) * HJD_SYNC_WG) << lw, lw};
+    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), sl.w0, lw, s_stream);
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
     const uint32_t i = (blockIdx.x - im.syncwg0) * HJD_SYNC_WG + tid;
@@ -274,7 +306,6 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
     const uint32_t g = im.sub0 + i;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, total_bits);
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
     const uint32_t nby = im.nby, nb = im.nb;
 
     uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
     if (valid) {
         if (launch_idx == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            decode_span<false>(w, s_lut, &s_slow, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false>(sl, s_lut, &s_slow, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
         } else {
@@ -309,7 +340,10 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
     s_ezm[tid] = ezm;
     __syncthreads();
 
+    uint32_t ndec = (valid && launch_idx == 0) ? 1u : 0u;
+    int iters = 0;
     for (int iter = 0; iter <= HJD_SYNC_WG; iter++) {
+        iters = iter;
         uint32_t wp, wzm;
         if (i == 0) {
             wp = 0;
@@ -326,11 +360,12 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
             dc0 = dc1 = dc2 = 0;
-            decode_span<false>(w, s_lut, &s_slow, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false>(sl, s_lut, &s_slow, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
             uzm = wzm;
+            ndec++;
         }
         __syncthreads();
         if (changed) {
@@ -352,6 +387,12 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int launch_id
         r.dc[2] = (int16_t)dc2;
         r.pad = 0;
         P.sub[g] = r;
+    }
+    // diagnostics
+    atomicAdd(&P.st[ii].sync_decodes, ndec);
+    if (tid == 0) {
+        atomicAdd(&P.st[ii].sync_iters, (uint32_t)iters);
+        atomicMax(&P.st[ii].sync_iters_max, (uint32_t)iters);
     }
 }
 
@@ -408,11 +449,15 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_lut[HJD_SLOTS * HJD_LUT_SIZE];
     __shared__ __attribute__((aligned(16))) SlowTab s_slow;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_stream[];
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.syncwg0; });
     const HjdImage &im = P.img[ii];
     load_tables(&P.tabs[im.tabset], s_lut, &s_slow);
+    const uint32_t lw = P.log2_words;
+    const StreamLds sl = {s_stream, ((blockIdx.x - im.syncwg0) * HJD_SYNC_WG) << lw, lw};
+    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), sl.w0, lw, s_stream);
     __syncthreads();
 
     const uint32_t S = P.subseq_bits;
@@ -422,7 +467,6 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     if (i >= nsub) return;
     const uint32_t g = im.sub0 + i;
     const uint32_t end = min(i * S + S, total_bits);
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
 
     uint32_t p = 0, zm = 0;
     if (i > 0) {
@@ -436,7 +480,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     const HjdSubStart st = P.substart[g];
     uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
     int dc0 = st.pred[0], dc1 = st.pred[1], dc2 = st.pred[2];
-    decode_span<true>(w, s_lut, &s_slow, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2, P.coef + im.coef_off,
+    decode_span<true>(sl, s_lut, &s_slow, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2, P.coef + im.coef_off,
                       im.nblocks, flags);
     if (flags) atomicOr(&P.st[ii].flags, flags);
 }
@@ -486,6 +530,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ float s_cosT[64];          // [u][x] = COS[x][u]
     __shared__ float s_cos[64];           // [v][y] = COS[y][v]  (same matrix, named for its use)
     __shared__ uint8_t s_qt[3][64];
+    __shared__ uint8_t s_pos[64];
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
@@ -503,23 +548,39 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         s_cos[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
     }
     if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
+    if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
+    if (tid < MAXGB) s_mask[tid] = 0;
     __syncthreads();
 
-    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180): one wave per block,
-    // lane = u*8+v reads zig-zag slot ZZ[v*8+u]; int16 wrap as the reference's (short)(int) cast
+    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180).  The group's
+    // coefficient rows are contiguous: one coalesced 16-byte load (8 zig-zag slots) per thread and
+    // step; only non-zero values are scattered to their (u,v) slot and flagged in the block's mask.
+    // int16 wrap of the product as the reference's (short)(int) cast.
     {
-        const uint32_t lane = tid & 63, wv = tid >> 6;
-        const uint32_t u = lane >> 3, v = lane & 7;
-        const uint32_t zz = c_zz[v * 8 + u];
-        const int16_t *cbase = P.coef + im.coef_off + (size_t)b0 * 64;
-        for (uint32_t blk = wv; blk < KB; blk += 4) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.coef + im.coef_off + (size_t)b0 * 64);
+        const uint32_t n4 = KB * 8;
+        for (uint32_t k = tid; k < n4; k += 256) {
+            const uint4 v = src[k];
+            if ((v.x | v.y | v.z | v.w) == 0u) continue;
+            const uint32_t blk = k >> 3, z0 = (k & 7) * 8;
             const uint32_t mm = blk % nb;
             const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
-            const int c = cbase[(size_t)blk * 64 + zz];
-            const int16_t nat = (int16_t)(c * (int)s_qt[comp][zz]);
-            s_coef[blk][lane] = nat;
-            const uint64_t mk = __ballot(nat != 0);
-            if (lane == 0) s_mask[blk] = mk;
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            uint64_t mk = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = (int)(int16_t)(wd[j >> 1] >> ((j & 1) * 16));
+                if (c != 0) {
+                    const uint32_t zz = z0 + j;
+                    const int16_t nat = (int16_t)(c * (int)s_qt[comp][zz]);
+                    if (nat != 0) {
+                        const uint32_t pos = s_pos[zz];
+                        s_coef[blk][pos] = nat;
+                        mk |= 1ull << pos;
+                    }
+                }
+            }
+            if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), (unsigned long long)mk);
         }
     }
     __syncthreads();
@@ -644,6 +705,12 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         if (e_ != hipSuccess) return (int)e_;      \
     } while (0)
 
+static inline uint32_t hjd_stream_lds_bytes(uint32_t lw)
+{
+    const uint32_t nwords = ((uint32_t)HJD_SYNC_WG << lw) + 8;
+    return (nwords + (nwords >> lw) + 4) * 4;
+}
+
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s)
 {
     if (!nchunks) return 0;
@@ -657,7 +724,9 @@ int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s)
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int launch_idx, hipStream_t s)
 {
     if (!nwg) return 0;
-    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), 0, s, P, launch_idx);
+    const uint32_t lds = hjd_stream_lds_bytes(P.log2_words);
+    if (lds > 40000 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P, launch_idx);
     HJD_LAUNCH_CHECK();
     return 0;
 }
@@ -673,7 +742,9 @@ int hjd_launch_scan(const HjdParams &P, hipStream_t s)
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
 {
     if (!nwg) return 0;
-    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), 0, s, P);
+    const uint32_t lds = hjd_stream_lds_bytes(P.log2_words);
+    if (lds > 40000 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }

@@ -135,7 +135,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     d->device = device;
     if (opt) {
         if (opt->subseq_bits) {
-            if (opt->subseq_bits < 64 || opt->subseq_bits > 4096 || (opt->subseq_bits % 32)) {
+            if (opt->subseq_bits < 64 || opt->subseq_bits > 2048 || (opt->subseq_bits & (opt->subseq_bits - 1))) {
                 delete d;
                 hjd_set_last_status(HJD_ERR_ARG);
                 return nullptr;
@@ -145,7 +145,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
-    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && atoi(e) % 32 == 0) d->subseq_bits = (uint32_t)atoi(e);
+    if (e && atoi(e) >= 64 && atoi(e) <= 2048 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
     return d;
 }
 
@@ -253,7 +253,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.raw_off = raw_cur;
         raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
         im.ustream_off = us_cur;
-        us_cur += align_up((size_t)im.scan_len + 64, 256);
+        us_cur += align_up((size_t)im.nsyncwg * HJD_SYNC_WG * (S / 8) + 64, 256);
         im.coef_off = coef_cur;
         coef_cur += (size_t)im.nblocks * 64;
         // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
@@ -273,7 +273,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     b->ustream_bytes = us_cur;
     b->coef_elems = coef_cur;
     b->out_total = out_cur;
-    b->state.assign(b->nimg, HjdImageState{0, 0, 0, 0});
+    b->state.assign(b->nimg, HjdImageState{});
     if (!b->nimg) return HJD_OK;
 
     // upload
@@ -313,6 +313,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.out = b->d_out;
     P.nimg = b->nimg;
     P.subseq_bits = S;
+    P.log2_words = 0;
+    while ((32u << P.log2_words) < S) P.log2_words++;
     return HJD_OK;
 }
 
@@ -546,6 +548,19 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     const size_t ne = (size_t)b->img[di].nblocks * 64;
     if (elems < ne) return HJD_ERR_ARG;
     HIPCHK(hipMemcpy(dst, b->d_coef + b->img[di].coef_off, ne * 2, hipMemcpyDeviceToHost));
+    return HJD_OK;
+}
+
+extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)
+{
+    if (!b || !stats4 || i < 0 || i >= b->n || b->dev_index[i] < 0) return HJD_ERR_ARG;
+    const HjdImageState &st = b->state[b->dev_index[i]];
+    const HjdImage &im = b->img[b->dev_index[i]];
+    stats4[0] = st.sync_iters;
+    stats4[1] = st.sync_decodes;
+    stats4[2] = st.sync_iters_max;
+    stats4[3] = (uint32_t)(((uint64_t)st.ustream_len * 8 + b->dec->subseq_bits - 1) / b->dec->subseq_bits);
+    (void)im;
     return HJD_OK;
 }
 

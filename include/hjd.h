@@ -108,7 +108,7 @@ typedef enum hjd_out_format {
 } hjd_out_format;
 
 typedef struct hjd_options {
-    int subseq_bits;     /* entropy-decode subsequence size in bits (multiple of 32, 64..4096); 0 = default */
+    int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..2048); 0 = default */
     int sync_launches;   /* speculative synchronisation launches before verification; 0 = default */
     int reserved[6];
 } hjd_options;
@@ -152,6 +152,11 @@ int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const c
  * hjd_batch_collect_timing (call it after the stream has been synchronised) averages them. */
 int hjd_batch_enable_timing(hjd_batch *b, int max_runs);
 int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **stage_names, int cap, int *runs);
+
+/* Diagnostics of the last finished run for image i: stats4 = {sum of refinement iterations over
+ * synchronisation workgroups, subsequence decodes executed while synchronising, max iterations of one
+ * workgroup, number of subsequences}. */
+int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
 
 /* Convenience: decode N host JPEGs to N caller-provided host buffers (RGB or BMP). */
 int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
