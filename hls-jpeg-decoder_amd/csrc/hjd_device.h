@@ -19,18 +19,24 @@
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 
 // Huffman decode tables of one distinct (DC/AC x 3 components) configuration.
-// lut entry (u16): bits 0-4 code length (0 = longer than HJD_LUT_BITS -> slow path),
-// bits 5-8 number of value bits s, bits 9-15 zig-zag advance:
-//   DC symbol n          -> s = n, adv = 1
-//   AC (r,s>0)           -> adv = r + 1 (coefficient lands at z + r)
-//   AC EOB (0,0)         -> adv = 64;  ZRL (15,0) -> adv = 16;  other (r,0) -> adv = 0
-//   (loadjpg.cpp:768-808)
+// Primary table: indexed by the next HJD_LUT_BITS bits.  Entry (u16):
+//   bits 0-4 code length (1..16), bits 5-8 number of value bits s, bits 9-15 zig-zag advance:
+//     DC symbol n          -> s = n, adv = 1
+//     AC (r,s>0)           -> adv = r + 1 (coefficient lands at z + r)
+//     AC EOB (0,0)         -> adv = 64;  ZRL (15,0) -> adv = 16;  other (r,0) -> adv = 0
+//     (loadjpg.cpp:768-808)
+//   code length 0: the code is longer than HJD_LUT_BITS; bits 5-15 = 1 + index of the secondary
+//   table for this prefix (0 = no code has this prefix).  Secondary tables are indexed by the next
+//   HJD_SEC_BITS bits and hold entries of the same format (length 0 = no such code).
+#define HJD_SEC_BITS 6
+#define HJD_MAX_SEC 64
 struct HjdTableSet {
+    uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)
+    uint32_t nsec;       // secondary tables in use
+    uint32_t slot_pack;  // 6 x 4 bits: slot (component*2 + isAC) -> primary table index
+    uint32_t pad;
     uint16_t lut[HJD_SLOTS][HJD_LUT_SIZE];
-    uint16_t mincode[HJD_SLOTS][17]; // canonical slow path: first code of length k
-    uint16_t count[HJD_SLOTS][17];   // number of codes of length k
-    uint16_t first[HJD_SLOTS][17];   // index of the first symbol of length k
-    uint16_t sym_entry[HJD_SLOTS][256]; // (s | adv << 4) per symbol index, same meaning as the lut fields
+    uint16_t sec[HJD_MAX_SEC][1 << HJD_SEC_BITS];
 };
 
 struct HjdImage {
@@ -46,8 +52,10 @@ struct HjdImage {
     uint32_t nchunks;
     uint32_t sub0;          // first subsequence (global numbering, capacity-based)
     uint32_t nsub_cap;      // capacity: ceil(scan_len*8 / subseq_bits)
-    uint32_t syncwg0;       // first synchronisation workgroup
+    uint32_t syncwg0;       // first synchronisation workgroup (overlapped tiling)
     uint32_t nsyncwg;
+    uint32_t writewg0;      // first final-pass workgroup (256 subsequences each)
+    uint32_t nwritewg;
     uint32_t group0;        // first IDCT/colour workgroup
     uint32_t groups_per_row;
     uint32_t ngroups;

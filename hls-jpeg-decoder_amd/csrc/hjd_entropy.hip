@@ -1,0 +1,358 @@
+// hjd_entropy.hip — Huffman VLC decode of the scan on gfx950 (MI355X, CDNA4).
+//   k_sync    ProcessHuffmanBlock, speculative: find the decoder state at every subsequence start
+//   k_write   ProcessHuffmanBlock, final pass: coefficients out            (loadjpg.cpp:499-863)
+//
+// The scan of a baseline JPEG is one bit-serial string.  It is cut into fixed-size SUBSEQUENCES
+// (S bits), one per lane.  Huffman streams self-synchronise: a decoder started at a wrong
+// position/state soon falls into step with the true decode.  Each lane decodes its subsequence
+// from a guessed start state, then again from the end state of its predecessor, until
+// start == predecessor's end everywhere in the workgroup.  Workgroups overlap by a few warm-up
+// subsequences, so the first owned lane of every workgroup has (with overwhelming probability)
+// the true state; k_write re-checks start == predecessor's end for EVERY subsequence across
+// workgroup borders, and the host re-synchronises if that induction step ever fails.  Outputs
+// are written only by k_write, so speculation never reaches them.
+//
+// LDS plan per workgroup (256 lanes):
+//   stream : the workgroup's span of the bit string, TRANSPOSED — word k of row (=lane) i at
+//            [k*257 + i], rows extended by the first two words of the next row — so that a
+//            lane's next word is a constant stride away and lanes reading the same k hit
+//            consecutive banks.  Filled once with coalesced 16-byte loads.
+//   lut    : primary Huffman tables (10-bit index), secondary tables for longer codes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hjd_device.h"
+#include "hjd_kernels.h"
+#include "hjd_kutil.h"
+
+#define ROWSTRIDE (HJD_SYNC_WG + 1) // words between successive words of one row
+
+struct EntropyLds {
+    const uint32_t *stream;
+    const uint16_t *lut; // [nlut][1024]
+    const uint16_t *sec; // [nsec][64]
+};
+
+// stage rows [row0, row0+256) of the image's word stream `w` (2^lw words per row)
+__device__ __forceinline__ void stage_stream(const uint32_t *__restrict__ w, uint32_t row0, uint32_t lw,
+                                             uint32_t *s_stream)
+{
+    const uint32_t wps = 1u << lw;
+    const uint32_t nwords = (HJD_SYNC_WG << lw) + 4; // + first words of the row after the last
+    const uint4 *src = reinterpret_cast<const uint4 *>(w + ((size_t)row0 << lw));
+    for (uint32_t q = threadIdx.x; q < nwords / 4; q += blockDim.x) {
+        const uint4 v = src[q];
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t g = 4 * q + j;
+            const uint32_t i = g >> lw, k = g & (wps - 1);
+            if (i < HJD_SYNC_WG) s_stream[k * ROWSTRIDE + i] = vv[j];
+            if (k < 2 && i >= 1) s_stream[(wps + k) * ROWSTRIDE + (i - 1)] = vv[j]; // row extension
+        }
+    }
+}
+
+__device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
+{
+    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * 2 / 16), ns = ts->nsec * (64 * 2 / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ts->lut[0][0]);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
+    for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) dst[k] = src[k];
+    src = reinterpret_cast<const uint4 *>(&ts->sec[0][0]);
+    dst = reinterpret_cast<uint4 *>(s_sec);
+    for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) dst[k] = src[k];
+}
+
+// byte offset of the primary table for (component, DC/AC) from the packed slot map
+__device__ __forceinline__ uint32_t table_base(uint32_t slot_pack, uint32_t comp, uint32_t isac)
+{
+    return ((slot_pack >> ((comp * 2u + isac) * 4u)) & 7u) * (HJD_LUT_SIZE * 2u);
+}
+
+// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
+//   WRITE = false: nblk counts blocks completed, dc0..2 sum the DC differences   (synchronisation)
+//   WRITE = true : nblk is the absolute block index, dc0..2 the running predictors; coefficients
+//                  are stored in zig-zag order (the DCT[] array of loadjpg.cpp:499-863)
+// `row` is the lane's row in the staged stream, `row_bit0` the absolute bit position of its first bit.
+template <bool WRITE>
+__device__ __forceinline__ void decode_span(const EntropyLds &L, uint32_t row, uint32_t row_bit0, uint32_t slot_pack,
+                                            uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                            uint32_t end, uint32_t &nblk, int &dc0, int &dc1, int &dc2,
+                                            int16_t *__restrict__ coef, uint32_t nblocks, uint32_t &flags)
+{
+    // bit reader: window = alignbit(hi, lo, sh); o = 32 - sh bits of hi are consumed (o in [1,32])
+    const uint32_t rel = p - row_bit0;
+    const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+    const uint32_t *sp = L.stream + k0 * ROWSTRIDE + row;
+    const uint32_t a = sp[0], b = sp[ROWSTRIDE];
+    uint32_t hi = a, lo = o0 ? b : a;
+    uint32_t sh = (32u - o0) & 31u;
+    const uint32_t *nx = sp + (o0 ? 2 * ROWSTRIDE : ROWSTRIDE);
+
+    uint32_t comp = m < nby ? 0u : m - nby + 1u;
+    uint32_t tb_ac = table_base(slot_pack, comp, 1u);
+    uint32_t tb = z ? tb_ac : table_base(slot_pack, comp, 0u);
+    const char *lutb = reinterpret_cast<const char *>(L.lut);
+
+    while (p < end && (!WRITE || nblk < nblocks)) {
+        const uint32_t nxt = *nx; // next word, fetched alongside the table lookup
+        const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, sh);
+        uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
+        if ((e & 31u) == 0u) {
+            // code longer than HJD_LUT_BITS: second-level table on the next 6 bits (IsInHuffmanCodes,
+            // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
+            const uint32_t sub = e >> 5;
+            e = sub ? L.sec[(sub - 1u) * 64u + ((win >> 16) & 63u)] : 0u;
+            if ((e & 31u) == 0u) {
+                if (WRITE) flags |= HJD_FLAG_BAD_CODE;
+                e = 16u; // skip 16 bits: any progress will do, the result is discarded or flagged
+            }
+        }
+        const uint32_t len = e & 31u, s = (e >> 5) & 15u, adv = e >> 9;
+        // value bits + DetermineSign (loadjpg.cpp:396-409)
+        const uint32_t vb = ((win << len) >> 1) >> (31u - s);
+        const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
+        const bool isdc = z == 0u;
+        const int dval = isdc ? val : 0; // DC: loadjpg.cpp:619-667
+        dc0 += comp == 0u ? dval : 0;
+        dc1 += comp == 1u ? dval : 0;
+        dc2 += comp == 2u ? dval : 0;
+        if (WRITE) {
+            const uint32_t zw = isdc ? 0u : z + adv - 1u; // AC run/size: loadjpg.cpp:776-808
+            const int16_t cv = isdc ? (int16_t)(comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2)) : (int16_t)val;
+            if (isdc || s != 0u) {
+                if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = cv;
+                else flags |= HJD_FLAG_OVERRUN;
+            }
+        }
+        z += adv;
+        tb = isdc ? tb_ac : tb;
+        if (z >= 64u) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
+            z = 0u;
+            nblk++;
+            m++;
+            if (m == nb) m = 0u;
+            comp = m < nby ? 0u : m - nby + 1u;
+            tb = table_base(slot_pack, comp, 0u);
+            tb_ac = table_base(slot_pack, comp, 1u);
+        }
+        const uint32_t tot = len + s;
+        p += tot;
+        const int sh2 = (int)sh - (int)tot;
+        const bool roll = sh2 < 0;
+        hi = roll ? lo : hi;
+        lo = roll ? nxt : lo;
+        nx += roll ? ROWSTRIDE : 0;
+        sh = (uint32_t)sh2 & 31u;
+    }
+}
+
+// ---- stage 1: synchronisation ----------------------------------------------------------------
+// mode 0: workgroup g owns subsequences [g*Q, (g+1)*Q), Q = 256 - K, and additionally decodes the K
+//         subsequences before them as warm-up (their records belong to workgroup g-1).
+// mode 1: re-synchronisation (host fallback): 256 owned subsequences per workgroup, records
+//         reloaded, lane 0 takes its start from the previous workgroup's last record.
+
+__global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    __shared__ uint32_t s_ep[HJD_SYNC_WG], s_ezm[HJD_SYNC_WG];
+
+    const uint32_t tid = threadIdx.x;
+    const int ii = mode == 0 ? find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.syncwg0; })
+                             : find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t lwg = blockIdx.x - (mode == 0 ? im.syncwg0 : im.writewg0);
+    const uint32_t K = mode == 0 ? P.sync_overlap : 0u, Q = HJD_SYNC_WG - K;
+    const uint32_t own0 = lwg * Q, own1 = own0 + Q;
+    const uint32_t row0 = own0 >= K ? own0 - K : 0u;
+
+    uint32_t *s_stream = s_dyn;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn + P.lds_lut_word);
+    uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
+    const HjdTableSet *ts = &P.tabs[im.tabset];
+    load_tables(ts, s_lut, s_sec);
+    const uint32_t lw = P.log2_words;
+    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), row0, lw, s_stream);
+    const EntropyLds L = {s_stream, s_lut, s_sec};
+    const uint32_t slot_pack = ts->slot_pack;
+
+    const uint32_t S = P.subseq_bits;
+    const uint32_t total_bits = P.st[ii].ustream_len * 8u;
+    const uint32_t nsub = (total_bits + S - 1) / S;
+    const uint32_t i = row0 + tid;
+    const bool valid = i < nsub && i < own1;
+    const bool owned = valid && i >= own0;
+    const uint32_t g = im.sub0 + i;
+    const uint32_t sp = i * S;
+    const uint32_t end = min(sp + S, total_bits);
+    const uint32_t nby = im.nby, nb = im.nb;
+
+    uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
+    int dc0 = 0, dc1 = 0, dc2 = 0;
+    uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the workgroup
+    uint32_t ndec = 0;
+    __syncthreads();
+
+    if (valid) {
+        if (mode == 0) {
+            uint32_t p = sp, z = 0, m = 0;
+            decode_span<false>(L, tid, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            ep = p;
+            ezm = z | (m << 8);
+            ndec = 1;
+        } else {
+            const HjdSub r = P.sub[g];
+            ep = r.e_p;
+            ezm = r.e_zm;
+            up = r.u_p;
+            uzm = r.u_zm;
+            nblk = r.nblk;
+            dc0 = r.dc[0];
+            dc1 = r.dc[1];
+            dc2 = r.dc[2];
+            if (tid == 0 && i > 0) {
+                const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
+                if (pe.x >= sp && pe.x < sp + 32u) { // a record of this run always ends inside the next word
+                    ext_p = pe.x;
+                    ext_zm = pe.y;
+                }
+            }
+        }
+    }
+    s_ep[tid] = ep;
+    s_ezm[tid] = ezm;
+    __syncthreads();
+
+    int iters = 0;
+    for (int iter = 0; iter <= HJD_SYNC_WG; iter++) {
+        iters = iter;
+        uint32_t wp, wzm;
+        if (i == 0) {
+            wp = 0;
+            wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
+        } else if (tid == 0) {
+            wp = ext_p;
+            wzm = ext_zm;
+        } else {
+            wp = s_ep[tid - 1];
+            wzm = s_ezm[tid - 1];
+        }
+        const bool changed = valid && (wp != up || wzm != uzm);
+        if (changed) {
+            uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
+            nblk = 0;
+            dc0 = dc1 = dc2 = 0;
+            decode_span<false>(L, tid, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            ep = p;
+            ezm = z | (m << 8);
+            up = wp;
+            uzm = wzm;
+            ndec++;
+        }
+        __syncthreads();
+        if (changed) {
+            s_ep[tid] = ep;
+            s_ezm[tid] = ezm;
+        }
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
+    }
+
+    if (owned) {
+        HjdSub r;
+        r.e_p = ep;
+        r.e_zm = ezm;
+        r.u_p = up;
+        r.u_zm = uzm;
+        r.nblk = nblk;
+        r.dc[0] = (int16_t)dc0;
+        r.dc[1] = (int16_t)dc1;
+        r.dc[2] = (int16_t)dc2;
+        r.pad = 0;
+        P.sub[g] = r;
+    }
+    // diagnostics
+    atomicAdd(&P.st[ii].sync_decodes, ndec);
+    if (tid == 0) {
+        atomicAdd(&P.st[ii].sync_iters, (uint32_t)iters);
+        atomicMax(&P.st[ii].sync_iters_max, (uint32_t)iters);
+    }
+}
+
+// ---- stage 3: final entropy decode, coefficients out ------------------------------------------
+
+__global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+
+    const uint32_t tid = threadIdx.x;
+    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t row0 = (blockIdx.x - im.writewg0) * HJD_SYNC_WG;
+
+    uint32_t *s_stream = s_dyn;
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn + P.lds_lut_word);
+    uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
+    const HjdTableSet *ts = &P.tabs[im.tabset];
+    load_tables(ts, s_lut, s_sec);
+    const uint32_t lw = P.log2_words;
+    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), row0, lw, s_stream);
+    const EntropyLds L = {s_stream, s_lut, s_sec};
+    const uint32_t slot_pack = ts->slot_pack;
+    __syncthreads();
+
+    const uint32_t S = P.subseq_bits;
+    const uint32_t total_bits = P.st[ii].ustream_len * 8u;
+    const uint32_t nsub = (total_bits + S - 1) / S;
+    const uint32_t i = row0 + tid;
+    if (i >= nsub) return;
+    const uint32_t g = im.sub0 + i;
+    const uint32_t end = min(i * S + S, total_bits);
+
+    uint32_t p = 0, zm = 0;
+    if (i > 0) {
+        const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
+        p = pe.x;
+        zm = pe.y;
+    }
+    uint32_t flags = 0;
+    const HjdSub me = P.sub[g];
+    if (me.u_p != p || me.u_zm != zm || p < i * S || p >= i * S + 32u)
+        flags |= HJD_FLAG_NOT_CONVERGED; // induction step failed: host re-synchronises
+    const HjdSubStart st = P.substart[g];
+    uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
+    int dc0 = st.pred[0], dc1 = st.pred[1], dc2 = st.pred[2];
+    if (!(flags & HJD_FLAG_NOT_CONVERGED))
+        decode_span<true>(L, tid, i * S, slot_pack, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2,
+                          P.coef + im.coef_off, im.nblocks, flags);
+    if (flags) atomicOr(&P.st[ii].flags, flags);
+}
+
+// ---- launch wrappers --------------------------------------------------------------------------
+
+static int set_dyn_lds(const void *fn, uint32_t bytes)
+{
+    if (bytes > 32768 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return -1;
+    return 0;
+}
+
+int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
+{
+    if (!nwg) return 0;
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes)) return -1;
+    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P, mode);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
+{
+    if (!nwg) return 0;
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), P.lds_bytes)) return -1;
+    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}

@@ -19,6 +19,10 @@ struct HjdParams {
     int nimg;
     uint32_t subseq_bits;      // power of two, 64..2048
     uint32_t log2_words;       // log2(subseq_bits / 32)
+    uint32_t sync_overlap;     // warm-up subsequences shared with the previous synchronisation workgroup
+    uint32_t lds_lut_word;     // entropy kernels' dynamic LDS: word offset of the primary tables
+    uint32_t lds_sec_word;     //                               word offset of the secondary tables
+    uint32_t lds_bytes;        //                               total bytes
 };
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);

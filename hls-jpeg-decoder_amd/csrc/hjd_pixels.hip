@@ -1,0 +1,233 @@
+// hjd_pixels.hip — block back end (gfx950): dequantise, 8x8 IDCT, chroma upsample, YCbCr->RGB,
+// output layout.
+//   k_idct_color   DecodeSingleBlock + YCrCB_to_RGB24_Block8x8 (+ WriteBMP24 layout)
+//                  (loadjpg.cpp:184-228, :867-932; openjpg.cpp:504-570)
+//
+// Compile with -ffp-contract=off: the reference's IDCT and colour arithmetic are fp32 with
+// one rounding per operation; an FMA would change output bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hjd_device.h"
+#include "hjd_kernels.h"
+#include "hjd_kutil.h"
+
+// ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
+
+// natural index -> zig-zag index (loadjpg.cpp:56-66)
+__constant__ uint8_t c_zz[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42,
+                                 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                                 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+                                 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// COS[x][u] = cosf(fl((2x+1)*u*3.14f)/16) exactly as the reference's x86-64/glibc-2.35 build
+// evaluates it (loadjpg.cpp:108,120).  A table, never recomputed: entry [6][7]
+// is libm-specific, and PI = 3.14f makes the basis non-orthogonal, so no fast IDCT is bit-exact.
+__constant__ float c_cos[64] = {
+    0x1p+0f, 0x1.f62c08p-1f, 0x1.d910b8p-1f, 0x1.a9cc2p-1f, 0x1.6a2ecap-1f, 0x1.1ca9eep-1f, 0x1.886ecap-2f, 0x1.90f1bep-3f,
+    0x1p+0f, 0x1.a9cc2p-1f, 0x1.886ecap-2f, -0x1.8dbedp-3f, -0x1.699b2p-1f, -0x1.f6032cp-1f, -0x1.d9606ap-1f, -0x1.1d5756p-1f,
+    0x1p+0f, 0x1.1ca9eep-1f, -0x1.86ed1p-2f, -0x1.f6032cp-1f, -0x1.6ac236p-1f, 0x1.8a8b92p-3f, 0x1.d8706ep-1f, 0x1.aab36ap-1f,
+    0x1p+0f, 0x1.90f1bep-3f, -0x1.d8c0bap-1f, -0x1.1d5756p-1f, 0x1.690742p-1f, 0x1.aab36ap-1f, -0x1.83e8d8p-2f, -0x1.f6a4aep-1f,
+    0x1p+0f, -0x1.8dbedp-3f, -0x1.d9606ap-1f, 0x1.1b4e94p-1f, 0x1.6b556cp-1f, -0x1.a86f2p-1f, -0x1.8cf256p-2f, 0x1.f5869ep-1f,
+    0x1p+0f, -0x1.1bfc56p-1f, -0x1.89f044p-2f, 0x1.f67ccap-1f, -0x1.68731cp-1f, -0x1.9a88c4p-3f, 0x1.da4da2p-1f, -0x1.a7851ep-1f,
+    0x1p+0f, -0x1.a9581p-1f, 0x1.856b06p-2f, 0x1.9756cp-3f, -0x1.6be866p-1f, 0x1.f6cc3cp-1f, -0x1.d77dbp-1f, 0x1.1895aep-1f,
+    0x1p+0f, -0x1.f6032cp-1f, 0x1.d8706ep-1f, -0x1.a86f2p-1f, 0x1.67dec4p-1f, -0x1.19442cp-1f, 0x1.7f609p-2f, -0x1.7a87f6p-3f};
+
+#define MAXGB (HJD_GROUP_MCUS * 6) // blocks per workgroup
+
+__device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ConvertYCrCbtoRGB as called at loadjpg.cpp:918 (:867-880), one rounding per operation
+__device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, uint32_t &r, uint32_t &g, uint32_t &b)
+{
+    const float fy = (float)y, fcb = (float)(cb - 128), fcr = (float)(cr - 128);
+    const float red = fy + 1.402f * fcr;
+    const float green = (fy - 0.34414f * fcb) - 0.71414f * fcr;
+    const float blue = fy + 1.772f * fcb;
+    r = clamp255((int)red);
+    g = clamp255((int)green);
+    b = clamp255((int)blue);
+}
+
+__global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
+{
+    __shared__ int16_t s_coef[MAXGB][64]; // dequantised, index u*8+v (u = horizontal frequency)
+    __shared__ uint64_t s_mask[MAXGB];    // bit u*8+v set where the coefficient is non-zero
+    __shared__ __attribute__((aligned(4))) uint8_t s_pix[MAXGB][64]; // decoded 8x8 tiles, row-major
+    __shared__ float s_cosT[64];          // [u][x] = COS[x][u]
+    __shared__ float s_cos[64];           // [v][y] = COS[y][v]  (same matrix, named for its use)
+    __shared__ uint8_t s_qt[3][64];
+    __shared__ uint8_t s_pos[64];
+
+    const uint32_t tid = threadIdx.x;
+    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t lg = blockIdx.x - im.group0;
+    const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;
+    const uint32_t mcu_first = gx * HJD_GROUP_MCUS;
+    const uint32_t K = min((uint32_t)HJD_GROUP_MCUS, im.mcux - mcu_first);
+    const uint32_t nb = im.nb, nby = im.nby, hf = im.hf, vf = im.vf;
+    const uint32_t KB = K * nb;
+    const uint32_t b0 = (mrow * im.mcux + mcu_first) * nb;
+
+    if (tid < 64) {
+        s_cosT[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
+        s_cos[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
+    }
+    if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
+    if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
+    if (tid < MAXGB) s_mask[tid] = 0;
+    __syncthreads();
+
+    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180).  The group's
+    // coefficient rows are contiguous: one coalesced 16-byte load (8 zig-zag slots) per thread and
+    // step; only non-zero values are scattered to their (u,v) slot and flagged in the block's mask.
+    // int16 wrap of the product as the reference's (short)(int) cast.
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.coef + im.coef_off + (size_t)b0 * 64);
+        const uint32_t n4 = KB * 8;
+        for (uint32_t k = tid; k < n4; k += 256) {
+            const uint4 v = src[k];
+            if ((v.x | v.y | v.z | v.w) == 0u) continue;
+            const uint32_t blk = k >> 3, z0 = (k & 7) * 8;
+            const uint32_t mm = blk % nb;
+            const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            uint64_t mk = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = (int)(int16_t)(wd[j >> 1] >> ((j & 1) * 16));
+                if (c != 0) {
+                    const uint32_t zz = z0 + j;
+                    const int16_t nat = (int16_t)(c * (int)s_qt[comp][zz]);
+                    if (nat != 0) {
+                        const uint32_t pos = s_pos[zz];
+                        s_coef[blk][pos] = nat;
+                        mk |= 1ull << pos;
+                    }
+                }
+            }
+            if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), (unsigned long long)mk);
+        }
+    }
+    __syncthreads();
+
+    // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Thread = (block, output column x),
+    // 8 row accumulators.  Terms are added in the reference's order (u outer, v inner); zero
+    // coefficients add +-0 and are skipped.  term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].
+    {
+        const uint32_t x = tid & 7;
+        for (uint32_t blk = tid >> 3; blk < KB; blk += 32) {
+            float acc[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) acc[y] = 0.0f;
+            uint64_t mk = s_mask[blk];
+            while (mk) {
+                const uint32_t j = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
+                mk &= mk - 1;
+                const uint32_t u = j >> 3, v = j & 7;
+                // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1
+                const float kk = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
+                const float t1 = kk * (float)s_coef[blk][j];
+                const float t2 = t1 * s_cosT[u * 8 + x];
+                const float4 ca = *reinterpret_cast<const float4 *>(&s_cos[v * 8]);
+                const float4 cb = *reinterpret_cast<const float4 *>(&s_cos[v * 8 + 4]);
+                acc[0] = acc[0] + t2 * ca.x;
+                acc[1] = acc[1] + t2 * ca.y;
+                acc[2] = acc[2] + t2 * ca.z;
+                acc[3] = acc[3] + t2 * ca.w;
+                acc[4] = acc[4] + t2 * cb.x;
+                acc[5] = acc[5] + t2 * cb.y;
+                acc[6] = acc[6] + t2 * cb.z;
+                acc[7] = acc[7] + t2 * cb.w;
+            }
+#pragma unroll
+            for (int y = 0; y < 8; y++) {
+                // (int)(0.25*sum) then short +128 then Clamp (loadjpg.cpp:123,136-137,219)
+                const int16_t t = (int16_t)(int)(acc[y] * 0.25f);
+                const int16_t lv = (int16_t)(t + 128);
+                s_pix[blk][y * 8 + x] = (uint8_t)clamp255(lv);
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932): nearest-neighbour chroma, clip at
+    // the image edge, then either m_rgb layout or WriteBMP24 layout (openjpg.cpp:555-568)
+    {
+        const uint32_t W = im.width, H = im.height;
+        const uint32_t mw = 8 * hf, mh = 8 * vf;
+        const uint32_t upr = K * 2 * hf; // 4-pixel units per row
+        const uint32_t nunits = upr * mh;
+        uint8_t *out = P.out + im.out_off;
+        const bool bmp = im.out_format == 1;
+        const uint32_t stride = im.out_stride;
+        for (uint32_t t = tid; t < nunits; t += 256) {
+            const uint32_t row = t / upr, ux = t % upr;
+            const uint32_t px = ux * 4;
+            const uint32_t k = px / mw, xin = px % mw;
+            const uint32_t gy = mrow * mh + row;
+            const uint32_t gxp = (mcu_first + k) * mw + xin;
+            if (gy >= H || gxp >= W) continue; // loadjpg.cpp:907-908
+            const uint32_t yblk = k * nb + (row >> 3) * hf + (xin >> 3);
+            const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[yblk][(row & 7) * 8 + (xin & 7)]);
+            const uint32_t cy = row / vf;
+            const uint8_t *pcb = &s_pix[k * nb + nby][cy * 8];
+            const uint8_t *pcr = &s_pix[k * nb + nby + 1][cy * 8];
+            uint32_t rr[4], gg[4], bb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t cx = (xin + j) / hf; // loadjpg.cpp:912
+                ycc_to_rgb((int)((ypix >> (8 * j)) & 0xFF), (int)pcb[cx], (int)pcr[cx], rr[j], gg[j], bb[j]);
+            }
+            const uint32_t nvalid = min(4u, W - gxp);
+            uint8_t *dst;
+            if (bmp) dst = out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3;
+            else dst = out + (size_t)gy * stride + (size_t)gxp * 3;
+            uint32_t c0[4], c2[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c0[j] = bmp ? bb[j] : rr[j];
+                c2[j] = bmp ? rr[j] : bb[j];
+            }
+            if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
+                uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+                d4[0] = c0[0] | (gg[0] << 8) | (c2[0] << 16) | (c0[1] << 24);
+                d4[1] = gg[1] | (c2[1] << 8) | (c0[2] << 16) | (gg[2] << 24);
+                d4[2] = c2[2] | (c0[3] << 8) | (gg[3] << 16) | (c2[3] << 24);
+            } else {
+                for (uint32_t j = 0; j < nvalid; j++) {
+                    dst[j * 3 + 0] = (uint8_t)c0[j];
+                    dst[j * 3 + 1] = (uint8_t)gg[j];
+                    dst[j * 3 + 2] = (uint8_t)c2[j];
+                }
+            }
+            if (bmp && gxp + nvalid == W) { // row padding (openjpg.cpp:563-567), written as zeros
+                for (uint32_t q = 3 * W; q < stride; q++) out[54 + (size_t)(H - 1 - gy) * stride + q] = 0;
+            }
+        }
+        if (bmp && lg == 0 && tid < 54) {
+            // stBMFH (openjpg.cpp:507-547): 'BM', file size, 0, 0, 54, 40, W, H, planes 1, 24 bpp, rest 0
+            const uint32_t fsz = W * H * 3 + H * (stride - 3 * W) + 54;
+            uint32_t v = 0;
+            if (tid == 0) v = 'B';
+            else if (tid == 1) v = 'M';
+            else if (tid >= 2 && tid < 6) v = (fsz >> (8 * (tid - 2))) & 0xFF;
+            else if (tid == 10) v = 54;
+            else if (tid == 14) v = 40;
+            else if (tid >= 18 && tid < 22) v = (W >> (8 * (tid - 18))) & 0xFF;
+            else if (tid >= 22 && tid < 26) v = (H >> (8 * (tid - 22))) & 0xFF;
+            else if (tid == 26) v = 1;
+            else if (tid == 28) v = 24;
+            out[tid] = (uint8_t)v;
+        }
+    }
+}
+
+int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s)
+{
+    if (!ngroups) return 0;
+    hipLaunchKernelGGL(k_idct_color, dim3(ngroups), dim3(256), 0, s, P);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}

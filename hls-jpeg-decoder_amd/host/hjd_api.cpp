@@ -29,7 +29,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct hjd_decoder {
     int device = 0;
     uint32_t subseq_bits = 1024;
-    int sync_launches = 2;
+    int sync_launches = 1;
+    uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
 };
 
 struct hjd_batch {
@@ -43,7 +44,7 @@ struct hjd_batch {
     std::vector<size_t> hdr_bytes;
     std::vector<HjdImageState> state;
     int out_format = 0;
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, ngroups = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0;
     size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
     uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
     // device
@@ -67,14 +68,13 @@ struct hjd_batch {
 
 // ---- Huffman table construction (GenHuffCodes / BuildHuffmanTable, openjpg.cpp:48-98) ----------
 
-static void build_slot(HjdTableSet &ts, int slot, const hjd_huff_spec &h, bool is_dc)
+// Fills primary table `ti` of the set from one DHT payload; long codes go to secondary tables.
+// Returns false when the set runs out of secondary tables.
+static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is_dc)
 {
-    memset(ts.lut[slot], 0, sizeof(ts.lut[slot]));
+    memset(ts.lut[ti], 0, sizeof(ts.lut[ti]));
     unsigned code = 0, idx = 0;
     for (int k = 1; k <= 16; k++) {
-        ts.mincode[slot][k] = (uint16_t)code;
-        ts.count[slot][k] = h.bits[k];
-        ts.first[slot][k] = (uint16_t)idx;
         for (unsigned j = 0; j < h.bits[k]; j++, idx++, code++) {
             const unsigned sym = h.vals[idx];
             unsigned s, adv;
@@ -87,16 +87,53 @@ static void build_slot(HjdTableSet &ts, int slot, const hjd_huff_spec &h, bool i
                 if (s) adv = r + 1;
                 else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
             }
-            ts.sym_entry[slot][idx] = (uint16_t)(s | (adv << 4));
+            const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
             if (k <= HJD_LUT_BITS) {
-                const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
                 const unsigned lo = code << (HJD_LUT_BITS - k), cnt = 1u << (HJD_LUT_BITS - k);
-                for (unsigned q = 0; q < cnt; q++) ts.lut[slot][lo + q] = e;
+                for (unsigned q = 0; q < cnt; q++) ts.lut[ti][lo + q] = e;
+            } else {
+                const unsigned prefix = code >> (k - HJD_LUT_BITS);
+                uint16_t &pe = ts.lut[ti][prefix];
+                if (pe == 0) {
+                    if (ts.nsec >= HJD_MAX_SEC) return false;
+                    memset(ts.sec[ts.nsec], 0, sizeof(ts.sec[0]));
+                    pe = (uint16_t)((ts.nsec + 1) << 5);
+                    ts.nsec++;
+                }
+                const unsigned si = (pe >> 5) - 1;
+                const unsigned rem = code & ((1u << (k - HJD_LUT_BITS)) - 1);
+                const unsigned sbits = HJD_SEC_BITS - (k - HJD_LUT_BITS);
+                for (unsigned q = 0; q < (1u << sbits); q++) ts.sec[si][(rem << sbits) + q] = e;
             }
         }
         code <<= 1;
     }
-    ts.mincode[slot][0] = ts.count[slot][0] = ts.first[slot][0] = 0;
+    return true;
+}
+
+// One table set per distinct (DC,AC) x (Y,Cb,Cr) configuration; identical payloads share a table.
+static bool build_tabset(HjdTableSet &ts, const hjd_jpeg_data &j)
+{
+    memset(&ts, 0, sizeof(ts));
+    const hjd_huff_spec *specs[HJD_SLOTS];
+    for (int c = 1; c <= 3; c++) {
+        specs[(c - 1) * 2 + 0] = &j.htdc[j.dc_table_index[c]];
+        specs[(c - 1) * 2 + 1] = &j.htac[j.ac_table_index[c]];
+    }
+    for (int sl = 0; sl < HJD_SLOTS; sl++) {
+        int ti = -1;
+        for (int q = 0; q < sl; q++)
+            if ((q & 1) == (sl & 1) && !memcmp(specs[q]->bits, specs[sl]->bits, 17) && !memcmp(specs[q]->vals, specs[sl]->vals, 256)) {
+                ti = (int)((ts.slot_pack >> (q * 4)) & 7);
+                break;
+            }
+        if (ti < 0) {
+            ti = (int)ts.nlut++;
+            if (!build_table(ts, ti, *specs[sl], (sl & 1) == 0)) return false;
+        }
+        ts.slot_pack |= (uint32_t)ti << (sl * 4);
+    }
+    return true;
 }
 
 static std::string tabset_key(const hjd_jpeg_data &j)
@@ -146,6 +183,12 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 2048 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
+    {   // warm-up: ~8192 bits of look-back, which a wrong start state does not survive in practice
+        uint32_t k = 8192 / d->subseq_bits;
+        d->sync_overlap = k < 4 ? 4 : (k > 64 ? 64 : k);
+        const char *ek = getenv("HJD_SYNC_OVERLAP");
+        if (ek && atoi(ek) >= 0 && atoi(ek) <= 128) d->sync_overlap = (uint32_t)atoi(ek);
+    }
     return d;
 }
 
@@ -186,6 +229,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, coef_cur = 0, out_cur = 0;
+    uint32_t max_nlut = 1, max_nsec = 0;
+    const uint32_t K = d->sync_overlap, Q = HJD_SYNC_WG - K;
 
     for (int i = 0; i < b->n; i++) {
         b->dev_index[i] = -1;
@@ -215,11 +260,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         auto it = tab_index.find(key);
         if (it == tab_index.end()) {
             HjdTableSet ts;
-            memset(&ts, 0, sizeof(ts));
-            for (int c = 1; c <= 3; c++) {
-                build_slot(ts, (c - 1) * 2 + 0, j.htdc[j.dc_table_index[c]], true);
-                build_slot(ts, (c - 1) * 2 + 1, j.htac[j.ac_table_index[c]], false);
+            if (!build_tabset(ts, j)) { // more long-code prefixes than the secondary tables hold
+                b->parse_status[i] = HJD_ERR_UNSUPPORTED;
+                continue;
             }
+            max_nlut = ts.nlut > max_nlut ? ts.nlut : max_nlut;
+            max_nsec = ts.nsec > max_nsec ? ts.nsec : max_nsec;
             it = tab_index.emplace(key, (uint32_t)tabs.size()).first;
             tabs.push_back(ts);
         }
@@ -231,8 +277,11 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
         b->nsub += im.nsub_cap;
         im.syncwg0 = b->nsyncwg;
-        im.nsyncwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
+        im.nsyncwg = (im.nsub_cap + Q - 1) / Q;
         b->nsyncwg += im.nsyncwg;
+        im.writewg0 = b->nwritewg;
+        im.nwritewg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
+        b->nwritewg += im.nwritewg;
         im.group0 = b->ngroups;
         im.groups_per_row = (im.mcux + HJD_GROUP_MCUS - 1) / HJD_GROUP_MCUS;
         im.ngroups = im.groups_per_row * im.mcuy;
@@ -253,7 +302,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.raw_off = raw_cur;
         raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
         im.ustream_off = us_cur;
-        us_cur += align_up((size_t)im.nsyncwg * HJD_SYNC_WG * (S / 8) + 64, 256);
+        us_cur += align_up(((size_t)im.nsub_cap + 2 * HJD_SYNC_WG) * (S / 8) + 64, 256); // staging reads whole rows past the end
         im.coef_off = coef_cur;
         coef_cur += (size_t)im.nblocks * 64;
         // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
@@ -315,6 +364,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.subseq_bits = S;
     P.log2_words = 0;
     while ((32u << P.log2_words) < S) P.log2_words++;
+    P.sync_overlap = K;
+    {   // dynamic LDS of the entropy kernels: transposed stream rows, then primary and secondary tables
+        const uint32_t stream_words = ((S / 32) + 2) * (HJD_SYNC_WG + 1);
+        P.lds_lut_word = (stream_words + 3) & ~3u;
+        P.lds_sec_word = P.lds_lut_word + max_nlut * HJD_LUT_SIZE / 2;
+        P.lds_bytes = (P.lds_sec_word + max_nsec * 32) * 4 + 16;
+    }
     return HJD_OK;
 }
 
@@ -379,18 +435,19 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         if ((rc = mark("unstuff"))) return rc;
         if (hjd_launch_unstuff(P, b->nchunks, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_sync"))) return rc;
-        for (int l = 0; l < b->dec->sync_launches; l++)
-            if (hjd_launch_sync(P, b->nsyncwg, l, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, b->nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        for (int l = 1; l < b->dec->sync_launches; l++)
+            if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
     } else {
-        if (hjd_launch_sync(P, b->nsyncwg, 1, s)) return HJD_ERR_INTERNAL;
-        if (hjd_launch_sync(P, b->nsyncwg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
     }
     if ((rc = mark("scan"))) return rc;
     if (hjd_launch_scan(P, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("coef_clear"))) return rc;
     HIPCHK(hipMemsetAsync(b->d_coef, 0, sizeof(int16_t) * b->coef_elems, s));
     if ((rc = mark("huff_write"))) return rc;
-    if (hjd_launch_write(P, b->nsyncwg, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_write(P, b->nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
     if (hjd_launch_idct_color(P, b->ngroups, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("end"))) return rc;
