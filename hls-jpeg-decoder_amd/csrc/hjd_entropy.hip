@@ -12,12 +12,13 @@
 // workgroup borders, and the host re-synchronises if that induction step ever fails.  Outputs
 // are written only by k_write, so speculation never reaches them.
 //
-// LDS plan per workgroup (256 lanes):
-//   stream : the workgroup's span of the bit string, TRANSPOSED — word k of row (=lane) i at
-//            [k*257 + i], rows extended by the first two words of the next row — so that a
-//            lane's next word is a constant stride away and lanes reading the same k hit
-//            consecutive banks.  Filled once with coalesced 16-byte loads.
-//   lut    : primary Huffman tables (10-bit index), secondary tables for longer codes.
+// Stream layout (written by k_unstuff_write): TRANSPOSED in groups of 64 subsequences — word k of
+// subsequence i lives at word ((i/64)*(wps+2) + k)*64 + i%64, and every row is extended by the
+// first two words of the next row.  A lane's next word is a constant 256 bytes away, and the 64
+// lanes of a wave (which advance roughly in step) touch a handful of cache lines per load.
+// LDS holds only the Huffman tables (primary 10-bit tables + secondary tables for longer codes),
+// so eight workgroups fit a CU.  Waves are independent after the table load: each wave owns 64 - K
+// subsequences plus K warm-up subsequences before them and iterates with __shfl_up / __ballot.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,32 +26,15 @@
 #include "hjd_kernels.h"
 #include "hjd_kutil.h"
 
-#define ROWSTRIDE (HJD_SYNC_WG + 1) // words between successive words of one row
-
 struct EntropyLds {
-    const uint32_t *stream;
     const uint16_t *lut; // [nlut][1024]
     const uint16_t *sec; // [nsec][64]
 };
 
-// stage rows [row0, row0+256) of the image's word stream `w` (2^lw words per row)
-__device__ __forceinline__ void stage_stream(const uint32_t *__restrict__ w, uint32_t row0, uint32_t lw,
-                                             uint32_t *s_stream)
+// address of word 0 of subsequence (row) i in the transposed stream; successive words are 64 words apart
+__device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t i, uint32_t lw)
 {
-    const uint32_t wps = 1u << lw;
-    const uint32_t nwords = (HJD_SYNC_WG << lw) + 4; // + first words of the row after the last
-    const uint4 *src = reinterpret_cast<const uint4 *>(w + ((size_t)row0 << lw));
-    for (uint32_t q = threadIdx.x; q < nwords / 4; q += blockDim.x) {
-        const uint4 v = src[q];
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t g = 4 * q + j;
-            const uint32_t i = g >> lw, k = g & (wps - 1);
-            if (i < HJD_SYNC_WG) s_stream[k * ROWSTRIDE + i] = vv[j];
-            if (k < 2 && i >= 1) s_stream[(wps + k) * ROWSTRIDE + (i - 1)] = vv[j]; // row extension
-        }
-    }
+    return w + ((size_t)(i >> 6) * ((1u << lw) + 2u)) * 64u + (i & 63u);
 }
 
 __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
@@ -70,34 +54,96 @@ __device__ __forceinline__ uint32_t table_base(uint32_t slot_pack, uint32_t comp
     return ((slot_pack >> ((comp * 2u + isac) * 4u)) & 7u) * (HJD_LUT_SIZE * 2u);
 }
 
+// ---- bit readers ------------------------------------------------------------------------------
+// window() = the next 32 bits; advance(n) consumes n <= 31 bits.  State: words hi, lo and sh = number
+// of unconsumed bits of hi (0..31); window = alignbit(hi, lo, sh).
+
+// k_sync: straight from the transposed stream in global memory (L1/L2-resident, lanes of a wave read
+// neighbouring addresses).  Two words are kept in flight so that a load is consumed two reloads
+// after it was issued; the loop issues no other vector-memory operation, so the wait is for old loads.
+struct ReaderGlobal {
+    uint32_t hi, lo, n1, n2, sh;
+    const uint32_t *gp;
+    __device__ __forceinline__ void init(const uint32_t *rowp, uint32_t rel)
+    {
+        const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+        const uint32_t *sp = rowp + k0 * 64u;
+        const uint32_t a = sp[0], b = sp[64], c = sp[128], d = sp[192];
+        hi = a;
+        lo = o0 ? b : a;
+        n1 = o0 ? c : b;
+        n2 = o0 ? d : c;
+        gp = sp + (o0 ? 256 : 192);
+        sh = (32u - o0) & 31u;
+    }
+    __device__ __forceinline__ void prefetch() {}
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+    __device__ __forceinline__ void advance(uint32_t tot)
+    {
+        const int sh2 = (int)sh - (int)tot;
+        if (sh2 < 0) {
+            hi = lo;
+            lo = n1;
+            n1 = n2;
+            n2 = *gp;
+            gp += 64;
+        }
+        sh = (uint32_t)sh2 & 31u;
+    }
+};
+
+// k_write: the wave's 64 rows are staged in LDS first ([k*64 + lane], coalesced 16-byte loads), so
+// that the loop's only vector-memory operations are the coefficient stores, which it never waits for
+// (loads and stores share one counter on gfx9-class hardware).
+struct ReaderLds {
+    uint32_t hi, lo, nxt, sh;
+    const uint32_t *nx;
+    __device__ __forceinline__ void init(const uint32_t *rowp, uint32_t rel)
+    {
+        const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+        const uint32_t *sp = rowp + k0 * 64u;
+        const uint32_t a = sp[0], b = sp[64];
+        hi = a;
+        lo = o0 ? b : a;
+        nx = sp + (o0 ? 128 : 64);
+        sh = (32u - o0) & 31u;
+        nxt = 0;
+    }
+    __device__ __forceinline__ void prefetch() { nxt = *nx; } // fetched alongside the table lookup
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+    __device__ __forceinline__ void advance(uint32_t tot)
+    {
+        const int sh2 = (int)sh - (int)tot;
+        const bool roll = sh2 < 0;
+        hi = roll ? lo : hi;
+        lo = roll ? nxt : lo;
+        nx += roll ? 64 : 0;
+        sh = (uint32_t)sh2 & 31u;
+    }
+};
+
 // Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
 //   WRITE = false: nblk counts blocks completed, dc0..2 sum the DC differences   (synchronisation)
 //   WRITE = true : nblk is the absolute block index, dc0..2 the running predictors; coefficients
 //                  are stored in zig-zag order (the DCT[] array of loadjpg.cpp:499-863)
-// `row` is the lane's row in the staged stream, `row_bit0` the absolute bit position of its first bit.
-template <bool WRITE>
-__device__ __forceinline__ void decode_span(const EntropyLds &L, uint32_t row, uint32_t row_bit0, uint32_t slot_pack,
-                                            uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
-                                            uint32_t end, uint32_t &nblk, int &dc0, int &dc1, int &dc2,
+// `rowp` points at word 0 of the lane's row (64 words between successive words), `row_bit0` is the
+// absolute bit position of the row's first bit.
+template <bool WRITE, class Reader>
+__device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
+                                            uint32_t slot_pack, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z,
+                                            uint32_t &m, uint32_t end, uint32_t &nblk, int &dc0, int &dc1, int &dc2,
                                             int16_t *__restrict__ coef, uint32_t nblocks, uint32_t &flags)
 {
-    // bit reader: window = alignbit(hi, lo, sh); o = 32 - sh bits of hi are consumed (o in [1,32])
-    const uint32_t rel = p - row_bit0;
-    const uint32_t k0 = rel >> 5, o0 = rel & 31u;
-    const uint32_t *sp = L.stream + k0 * ROWSTRIDE + row;
-    const uint32_t a = sp[0], b = sp[ROWSTRIDE];
-    uint32_t hi = a, lo = o0 ? b : a;
-    uint32_t sh = (32u - o0) & 31u;
-    const uint32_t *nx = sp + (o0 ? 2 * ROWSTRIDE : ROWSTRIDE);
-
+    Reader rd;
+    rd.init(rowp, p - row_bit0);
     uint32_t comp = m < nby ? 0u : m - nby + 1u;
     uint32_t tb_ac = table_base(slot_pack, comp, 1u);
     uint32_t tb = z ? tb_ac : table_base(slot_pack, comp, 0u);
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
     while (p < end && (!WRITE || nblk < nblocks)) {
-        const uint32_t nxt = *nx; // next word, fetched alongside the table lookup
-        const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, sh);
+        rd.prefetch();
+        const uint32_t win = rd.window();
         uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
         if ((e & 31u) == 0u) {
             // code longer than HJD_LUT_BITS: second-level table on the next 6 bits (IsInHuffmanCodes,
@@ -139,66 +185,59 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, uint32_t row, u
         }
         const uint32_t tot = len + s;
         p += tot;
-        const int sh2 = (int)sh - (int)tot;
-        const bool roll = sh2 < 0;
-        hi = roll ? lo : hi;
-        lo = roll ? nxt : lo;
-        nx += roll ? ROWSTRIDE : 0;
-        sh = (uint32_t)sh2 & 31u;
+        rd.advance(tot);
     }
 }
 
 // ---- stage 1: synchronisation ----------------------------------------------------------------
-// mode 0: workgroup g owns subsequences [g*Q, (g+1)*Q), Q = 256 - K, and additionally decodes the K
-//         subsequences before them as warm-up (their records belong to workgroup g-1).
-// mode 1: re-synchronisation (host fallback): 256 owned subsequences per workgroup, records
-//         reloaded, lane 0 takes its start from the previous workgroup's last record.
+// mode 0: wave w of an image owns subsequences [w*Q, (w+1)*Q), Q = 64 - K, and additionally decodes
+//         the K subsequences before them as warm-up (their records belong to wave w-1).
+// mode 1: re-synchronisation (host fallback): 64 owned subsequences per wave, records reloaded,
+//         lane 0 takes its start from the previous wave's last record.
 
 __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    __shared__ uint32_t s_ep[HJD_SYNC_WG], s_ezm[HJD_SYNC_WG];
 
-    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const int ii = mode == 0 ? find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.syncwg0; })
                              : find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
     const HjdImage &im = P.img[ii];
-    const uint32_t lwg = blockIdx.x - (mode == 0 ? im.syncwg0 : im.writewg0);
-    const uint32_t K = mode == 0 ? P.sync_overlap : 0u, Q = HJD_SYNC_WG - K;
-    const uint32_t own0 = lwg * Q, own1 = own0 + Q;
+    const uint32_t wv = (blockIdx.x - (mode == 0 ? im.syncwg0 : im.writewg0)) * (HJD_SYNC_WG / 64) + (threadIdx.x >> 6);
+    const uint32_t K = mode == 0 ? P.sync_overlap : 0u, Q = 64u - K;
+    const uint32_t own0 = wv * Q, own1 = own0 + Q;
     const uint32_t row0 = own0 >= K ? own0 - K : 0u;
 
-    uint32_t *s_stream = s_dyn;
-    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn + P.lds_lut_word);
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
     const HjdTableSet *ts = &P.tabs[im.tabset];
     load_tables(ts, s_lut, s_sec);
-    const uint32_t lw = P.log2_words;
-    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), row0, lw, s_stream);
-    const EntropyLds L = {s_stream, s_lut, s_sec};
+    const EntropyLds L = {s_lut, s_sec};
     const uint32_t slot_pack = ts->slot_pack;
+    const uint32_t lw = P.log2_words;
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = row0 + tid;
+    const uint32_t i = row0 + lane;
     const bool valid = i < nsub && i < own1;
     const bool owned = valid && i >= own0;
     const uint32_t g = im.sub0 + i;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, total_bits);
     const uint32_t nby = im.nby, nb = im.nb;
+    const uint32_t *rowp = row_base(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), i, lw);
 
     uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
     int dc0 = 0, dc1 = 0, dc2 = 0;
-    uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the workgroup
+    uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the wave
     uint32_t ndec = 0;
-    __syncthreads();
+    __syncthreads(); // tables are in LDS; from here on the waves run independently
 
     if (valid) {
         if (mode == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            decode_span<false>(L, tid, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderGlobal>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             ndec = 1;
@@ -212,7 +251,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
             dc0 = r.dc[0];
             dc1 = r.dc[1];
             dc2 = r.dc[2];
-            if (tid == 0 && i > 0) {
+            if (lane == 0 && i > 0) {
                 const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
                 if (pe.x >= sp && pe.x < sp + 32u) { // a record of this run always ends inside the next word
                     ext_p = pe.x;
@@ -221,42 +260,31 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
             }
         }
     }
-    s_ep[tid] = ep;
-    s_ezm[tid] = ezm;
-    __syncthreads();
 
-    int iters = 0;
-    for (int iter = 0; iter <= HJD_SYNC_WG; iter++) {
-        iters = iter;
-        uint32_t wp, wzm;
+    uint32_t iters = 0;
+    for (; iters <= 64u; iters++) {
+        uint32_t wp = __shfl_up(ep, 1, 64), wzm = __shfl_up(ezm, 1, 64);
+        if (lane == 0) {
+            wp = ext_p;
+            wzm = ext_zm;
+        }
         if (i == 0) {
             wp = 0;
             wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
-        } else if (tid == 0) {
-            wp = ext_p;
-            wzm = ext_zm;
-        } else {
-            wp = s_ep[tid - 1];
-            wzm = s_ezm[tid - 1];
         }
         const bool changed = valid && (wp != up || wzm != uzm);
+        if (!__ballot(changed)) break;
         if (changed) {
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
             dc0 = dc1 = dc2 = 0;
-            decode_span<false>(L, tid, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderGlobal>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
             uzm = wzm;
             ndec++;
         }
-        __syncthreads();
-        if (changed) {
-            s_ep[tid] = ep;
-            s_ezm[tid] = ezm;
-        }
-        if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
 
     if (owned) {
@@ -274,9 +302,9 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     }
     // diagnostics
     atomicAdd(&P.st[ii].sync_decodes, ndec);
-    if (tid == 0) {
-        atomicAdd(&P.st[ii].sync_iters, (uint32_t)iters);
-        atomicMax(&P.st[ii].sync_iters_max, (uint32_t)iters);
+    if (lane == 0) {
+        atomicAdd(&P.st[ii].sync_iters, iters);
+        atomicMax(&P.st[ii].sync_iters_max, iters);
     }
 }
 
@@ -286,29 +314,35 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
 
-    const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
     const HjdImage &im = P.img[ii];
-    const uint32_t row0 = (blockIdx.x - im.writewg0) * HJD_SYNC_WG;
 
-    uint32_t *s_stream = s_dyn;
-    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn + P.lds_lut_word);
+    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
     const HjdTableSet *ts = &P.tabs[im.tabset];
     load_tables(ts, s_lut, s_sec);
-    const uint32_t lw = P.log2_words;
-    stage_stream(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), row0, lw, s_stream);
-    const EntropyLds L = {s_stream, s_lut, s_sec};
+    const EntropyLds L = {s_lut, s_sec};
     const uint32_t slot_pack = ts->slot_pack;
-    __syncthreads();
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = row0 + tid;
+    const uint32_t i = (blockIdx.x - im.writewg0) * HJD_SYNC_WG + threadIdx.x;
+    // stage this wave's group of 64 rows: (wps+2) x 256 contiguous bytes of the transposed stream
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t rowwords = ((1u << P.log2_words) + 2u) * 64u;
+    uint32_t *s_rows = s_dyn + P.lds_stream_word + wv * rowwords;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(
+            row_base(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), i & ~63u, P.log2_words));
+        uint4 *dst = reinterpret_cast<uint4 *>(s_rows);
+        for (uint32_t q = lane; q < rowwords / 4; q += 64) dst[q] = src[q];
+    }
+    __syncthreads();
     if (i >= nsub) return;
     const uint32_t g = im.sub0 + i;
     const uint32_t end = min(i * S + S, total_bits);
+    const uint32_t *rowp = s_rows + lane;
 
     uint32_t p = 0, zm = 0;
     if (i > 0) {
@@ -324,7 +358,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
     int dc0 = st.pred[0], dc1 = st.pred[1], dc2 = st.pred[2];
     if (!(flags & HJD_FLAG_NOT_CONVERGED))
-        decode_span<true>(L, tid, i * S, slot_pack, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2,
+        decode_span<true, ReaderLds>(L, rowp, i * S, slot_pack, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2,
                           P.coef + im.coef_off, im.nblocks, flags);
     if (flags) atomicOr(&P.st[ii].flags, flags);
 }
@@ -342,8 +376,9 @@ static int set_dyn_lds(const void *fn, uint32_t bytes)
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 {
     if (!nwg) return 0;
-    if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes)) return -1;
-    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P, mode);
+    const uint32_t lds = P.lds_stream_word * 4; // tables only
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), lds)) return -1;
+    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P, mode);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -22,7 +22,8 @@ struct HjdParams {
     uint32_t sync_overlap;     // warm-up subsequences shared with the previous synchronisation workgroup
     uint32_t lds_lut_word;     // entropy kernels' dynamic LDS: word offset of the primary tables
     uint32_t lds_sec_word;     //                               word offset of the secondary tables
-    uint32_t lds_bytes;        //                               total bytes
+    uint32_t lds_stream_word;  //                               word offset of k_write's staged rows (= table bytes / 4)
+    uint32_t lds_bytes;        //                               total bytes (k_write)
 };
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);

@@ -51,9 +51,9 @@ __device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, uint32_t &r, u
 
 __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
 {
-    __shared__ int16_t s_coef[MAXGB][64]; // dequantised, index u*8+v (u = horizontal frequency)
+    __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index u*8+v (u = horizontal frequency); +2 pad: bank spread
     __shared__ uint64_t s_mask[MAXGB];    // bit u*8+v set where the coefficient is non-zero
-    __shared__ __attribute__((aligned(4))) uint8_t s_pix[MAXGB][64]; // decoded 8x8 tiles, row-major
+    __shared__ __attribute__((aligned(8))) uint8_t s_pix[MAXGB][72]; // decoded 8x8 tiles, row-major; +8 pad: bank spread
     __shared__ float s_cosT[64];          // [u][x] = COS[x][u]
     __shared__ float s_cos[64];           // [v][y] = COS[y][v]  (same matrix, named for its use)
     __shared__ uint8_t s_qt[3][64];

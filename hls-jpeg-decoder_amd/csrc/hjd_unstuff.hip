@@ -71,12 +71,21 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     uint32_t mask = unstuff_keepmask(im, P.raw, lc, &v, s_last);
     uint32_t total;
     uint32_t pos = base + block_excl_scan(__popc(mask), s_w, &total);
+    // Transposed stream (see hjd_entropy.hip): word k of subsequence i -> ((i/64)*(wps+2) + k)*64 + i%64,
+    // bytes MSB-first inside a word; words 0 and 1 of row i are repeated as words wps, wps+1 of row i-1.
     uint8_t *dst = P.ustream + im.ustream_off;
+    const uint32_t lw = P.log2_words, wps = 1u << lw;
     uint32_t words[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (mask & (1u << j)) {
-            dst[pos ^ 3u] = (uint8_t)(words[j >> 2] >> ((j & 3) * 8)); // MSB-first words
+            const uint8_t bv = (uint8_t)(words[j >> 2] >> ((j & 3) * 8));
+            const uint32_t wq = pos >> 2, i = wq >> lw, k = wq & (wps - 1u), bsel = 3u - (pos & 3u);
+            dst[(((size_t)(i >> 6) * (wps + 2u) + k) * 64u + (i & 63u)) * 4u + bsel] = bv;
+            if (k < 2u && i >= 1u) {
+                const uint32_t i1 = i - 1u;
+                dst[(((size_t)(i1 >> 6) * (wps + 2u) + wps + k) * 64u + (i1 & 63u)) * 4u + bsel] = bv;
+            }
             pos++;
         }
     }

@@ -185,9 +185,9 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     if (e && atoi(e) >= 64 && atoi(e) <= 2048 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
     {   // warm-up: ~8192 bits of look-back, which a wrong start state does not survive in practice
         uint32_t k = 8192 / d->subseq_bits;
-        d->sync_overlap = k < 4 ? 4 : (k > 64 ? 64 : k);
+        d->sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
         const char *ek = getenv("HJD_SYNC_OVERLAP");
-        if (ek && atoi(ek) >= 0 && atoi(ek) <= 128) d->sync_overlap = (uint32_t)atoi(ek);
+        if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) d->sync_overlap = (uint32_t)atoi(ek);
     }
     return d;
 }
@@ -230,7 +230,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, coef_cur = 0, out_cur = 0;
     uint32_t max_nlut = 1, max_nsec = 0;
-    const uint32_t K = d->sync_overlap, Q = HJD_SYNC_WG - K;
+    const uint32_t K = d->sync_overlap, Q = 64 - K; // per wave
 
     for (int i = 0; i < b->n; i++) {
         b->dev_index[i] = -1;
@@ -277,7 +277,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
         b->nsub += im.nsub_cap;
         im.syncwg0 = b->nsyncwg;
-        im.nsyncwg = (im.nsub_cap + Q - 1) / Q;
+        im.nsyncwg = ((im.nsub_cap + Q - 1) / Q + HJD_SYNC_WG / 64 - 1) / (HJD_SYNC_WG / 64); // 4 waves per workgroup
         b->nsyncwg += im.nsyncwg;
         im.writewg0 = b->nwritewg;
         im.nwritewg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
@@ -302,7 +302,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.raw_off = raw_cur;
         raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
         im.ustream_off = us_cur;
-        us_cur += align_up(((size_t)im.nsub_cap + 2 * HJD_SYNC_WG) * (S / 8) + 64, 256); // staging reads whole rows past the end
+        us_cur += ((size_t)im.nwritewg * (HJD_SYNC_WG / 64) + 2) * ((S / 32) + 2) * 256; // 64-row groups of wps+2 words, whole workgroups + slack for prefetch
         im.coef_off = coef_cur;
         coef_cur += (size_t)im.nblocks * 64;
         // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
@@ -366,10 +366,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     while ((32u << P.log2_words) < S) P.log2_words++;
     P.sync_overlap = K;
     {   // dynamic LDS of the entropy kernels: transposed stream rows, then primary and secondary tables
-        const uint32_t stream_words = ((S / 32) + 2) * (HJD_SYNC_WG + 1);
-        P.lds_lut_word = (stream_words + 3) & ~3u;
+        P.lds_lut_word = 0;
         P.lds_sec_word = P.lds_lut_word + max_nlut * HJD_LUT_SIZE / 2;
-        P.lds_bytes = (P.lds_sec_word + max_nsec * 32) * 4 + 16;
+        P.lds_stream_word = (P.lds_sec_word + max_nsec * 32 + 3) & ~3u;
+        P.lds_bytes = (P.lds_stream_word + (HJD_SYNC_WG / 64) * ((S / 32) + 2) * 64) * 4;
     }
     return HJD_OK;
 }
