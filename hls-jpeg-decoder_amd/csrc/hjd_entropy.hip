@@ -226,7 +226,16 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, total_bits);
     const uint32_t nby = im.nby, nb = im.nb;
-    const uint32_t *rowp = row_base(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), i, lw);
+    // stage this wave's 64 rows [row0, row0+64): they straddle at most two 64-row groups of the stream
+    const uint32_t rowwords = ((1u << lw) + 2u) * 64u;
+    uint32_t *s_rows = s_dyn + P.lds_stream_word + (threadIdx.x >> 6) * rowwords;
+    {
+        const uint32_t *wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
+        const uint32_t *src = row_base(wbase, i, lw);
+        if (valid) // a lane only ever reads its own row
+            for (uint32_t k = 0; k < (1u << lw) + 2u; k++) s_rows[k * 64u + lane] = src[k * 64u];
+    }
+    const uint32_t *rowp = s_rows + lane;
 
     uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
     int dc0 = 0, dc1 = 0, dc2 = 0;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     if (valid) {
         if (mode == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            decode_span<false, ReaderGlobal>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderLds>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             ndec = 1;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
             dc0 = dc1 = dc2 = 0;
-            decode_span<false, ReaderGlobal>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderLds>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
@@ -376,9 +385,8 @@ static int set_dyn_lds(const void *fn, uint32_t bytes)
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 {
     if (!nwg) return 0;
-    const uint32_t lds = P.lds_stream_word * 4; // tables only
-    if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), lds)) return -1;
-    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P, mode);
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes)) return -1;
+    hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P, mode);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -277,7 +277,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
         b->nsub += im.nsub_cap;
         im.syncwg0 = b->nsyncwg;
-        im.nsyncwg = ((im.nsub_cap + Q - 1) / Q + HJD_SYNC_WG / 64 - 1) / (HJD_SYNC_WG / 64); // 4 waves per workgroup
+        im.nsyncwg = ((im.nsub_cap + Q - 1) / Q + HJD_SYNC_WG / 64 - 1) / (HJD_SYNC_WG / 64); // whole workgroups of independent waves
         b->nsyncwg += im.nsyncwg;
         im.writewg0 = b->nwritewg;
         im.nwritewg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
