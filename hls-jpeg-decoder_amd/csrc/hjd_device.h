@@ -6,7 +6,8 @@
 //              stored at address k^3), image i at ustream_off
 //   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
 //   substart : exclusive prefix sums over sub (first block index, DC predictors)
-//   coef     : dense int16 coefficients, zig-zag order, 64 per block
+//   coef     : dense int16 coefficients, zig-zag order, 64 per block (slot 0 unused: DC lives in dcd/dca)
+//   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
 //   out      : RGB or BMP bytes
 #pragma once
 #include <stdint.h>
@@ -17,6 +18,7 @@
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
 #define HJD_SYNC_WG 512        // threads (= subsequences) per entropy workgroup: 8 independent waves sharing the tables
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
+#define HJD_DC_CHUNK 1024      // MCUs per DC-prediction workgroup
 
 // Huffman decode tables of one distinct (DC/AC x 3 components) configuration.
 // Primary table: indexed by the next HJD_LUT_BITS bits.  Entry (u16):
@@ -56,6 +58,8 @@ struct HjdImage {
     uint32_t nsyncwg;
     uint32_t writewg0;      // first final-pass workgroup (256 subsequences each)
     uint32_t nwritewg;
+    uint32_t dcchunk0;      // first DC-prediction chunk
+    uint32_t ndcchunk;
     uint32_t group0;        // first IDCT/colour workgroup
     uint32_t groups_per_row;
     uint32_t ngroups;
@@ -90,12 +94,9 @@ struct HjdSub {
     uint32_t u_p;    // start state this record was computed from
     uint32_t u_zm;
     uint32_t nblk;   // blocks completed inside
-    int16_t dc[3];   // sum of DC differences decoded inside, per component (mod 2^16)
-    int16_t pad;
+    uint32_t pad[3];
 };
 
 struct HjdSubStart {
     uint32_t blk0;   // index of the block in progress at the subsequence start
-    int16_t pred[3]; // DC predictors at the subsequence start
-    int16_t pad;
 };

@@ -48,10 +48,12 @@ __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_l
     for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) dst[k] = src[k];
 }
 
-// byte offset of the primary table for (component, DC/AC) from the packed slot map
-__device__ __forceinline__ uint32_t table_base(uint32_t slot_pack, uint32_t comp, uint32_t isac)
+// (DC | AC << 16) byte offsets of a component's primary tables, from the packed slot map
+__device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp)
 {
-    return ((slot_pack >> ((comp * 2u + isac) * 4u)) & 7u) * (HJD_LUT_SIZE * 2u);
+    const uint32_t dc = ((slot_pack >> (comp * 8u)) & 7u) * (HJD_LUT_SIZE * 2u);
+    const uint32_t ac = ((slot_pack >> (comp * 8u + 4u)) & 7u) * (HJD_LUT_SIZE * 2u);
+    return dc | (ac << 16);
 }
 
 // ---- bit readers ------------------------------------------------------------------------------
@@ -123,22 +125,24 @@ struct ReaderLds {
 };
 
 // Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
-//   WRITE = false: nblk counts blocks completed, dc0..2 sum the DC differences   (synchronisation)
-//   WRITE = true : nblk is the absolute block index, dc0..2 the running predictors; coefficients
-//                  are stored in zig-zag order (the DCT[] array of loadjpg.cpp:499-863)
+//   WRITE = false: nblk counts blocks completed                                   (synchronisation)
+//   WRITE = true : nblk is the absolute block index; AC coefficients are stored in zig-zag order
+//                  (the DCT[] array of loadjpg.cpp:499-863), DC DIFFERENCES go to dcd[] — DC
+//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcscan
 // `rowp` points at word 0 of the lane's row (64 words between successive words), `row_bit0` is the
-// absolute bit position of the row's first bit.
+// absolute bit position of the row's first bit.  tabY/tabCb/tabCr: byte offsets of the component's
+// (DC | AC << 16) primary tables.
 template <bool WRITE, class Reader>
 __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
-                                            uint32_t slot_pack, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z,
-                                            uint32_t &m, uint32_t end, uint32_t &nblk, int &dc0, int &dc1, int &dc2,
-                                            int16_t *__restrict__ coef, uint32_t nblocks, uint32_t &flags)
+                                            uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
+                                            uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
+                                            int16_t *__restrict__ coef, int16_t *__restrict__ dcd, uint32_t nblocks,
+                                            uint32_t &flags)
 {
     Reader rd;
     rd.init(rowp, p - row_bit0);
-    uint32_t comp = m < nby ? 0u : m - nby + 1u;
-    uint32_t tb_ac = table_base(slot_pack, comp, 1u);
-    uint32_t tb = z ? tb_ac : table_base(slot_pack, comp, 0u);
+    uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
+    uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
     while (p < end && (!WRITE || nblk < nblocks)) {
@@ -156,32 +160,27 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             }
         }
         const uint32_t len = e & 31u, s = (e >> 5) & 15u, adv = e >> 9;
-        // value bits + DetermineSign (loadjpg.cpp:396-409)
-        const uint32_t vb = ((win << len) >> 1) >> (31u - s);
-        const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
         const bool isdc = z == 0u;
-        const int dval = isdc ? val : 0; // DC: loadjpg.cpp:619-667
-        dc0 += comp == 0u ? dval : 0;
-        dc1 += comp == 1u ? dval : 0;
-        dc2 += comp == 2u ? dval : 0;
         if (WRITE) {
-            const uint32_t zw = isdc ? 0u : z + adv - 1u; // AC run/size: loadjpg.cpp:776-808
-            const int16_t cv = isdc ? (int16_t)(comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2)) : (int16_t)val;
-            if (isdc || s != 0u) {
-                if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = cv;
+            // value bits + DetermineSign (loadjpg.cpp:396-409)
+            const uint32_t vb = ((win << len) >> 1) >> (31u - s);
+            const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
+            if (isdc) {
+                dcd[nblk] = (int16_t)val;
+            } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
+                const uint32_t zw = z + adv - 1u;
+                if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = (int16_t)val;
                 else flags |= HJD_FLAG_OVERRUN;
             }
         }
         z += adv;
-        tb = isdc ? tb_ac : tb;
+        tb = isdc ? pair >> 16 : tb;
         if (z >= 64u) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
             nblk++;
-            m++;
-            if (m == nb) m = 0u;
-            comp = m < nby ? 0u : m - nby + 1u;
-            tb = table_base(slot_pack, comp, 0u);
-            tb_ac = table_base(slot_pack, comp, 1u);
+            m = (m + 1u == nb) ? 0u : m + 1u;
+            pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
+            tb = pair & 0xFFFFu;
         }
         const uint32_t tot = len + s;
         p += tot;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     const HjdTableSet *ts = &P.tabs[im.tabset];
     load_tables(ts, s_lut, s_sec);
     const EntropyLds L = {s_lut, s_sec};
-    const uint32_t slot_pack = ts->slot_pack;
+    const uint32_t tabY = table_pair(ts->slot_pack, 0), tabCb = table_pair(ts->slot_pack, 1), tabCr = table_pair(ts->slot_pack, 2);
     const uint32_t lw = P.log2_words;
 
     const uint32_t S = P.subseq_bits;
@@ -238,7 +237,6 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     const uint32_t *rowp = s_rows + lane;
 
     uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
-    int dc0 = 0, dc1 = 0, dc2 = 0;
     uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the wave
     uint32_t ndec = 0;
     __syncthreads(); // tables are in LDS; from here on the waves run independently
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     if (valid) {
         if (mode == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            decode_span<false, ReaderLds>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             ndec = 1;
@@ -257,9 +255,6 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
             up = r.u_p;
             uzm = r.u_zm;
             nblk = r.nblk;
-            dc0 = r.dc[0];
-            dc1 = r.dc[1];
-            dc2 = r.dc[2];
             if (lane == 0 && i > 0) {
                 const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
                 if (pe.x >= sp && pe.x < sp + 32u) { // a record of this run always ends inside the next word
@@ -283,11 +278,11 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
         }
         const bool changed = valid && (wp != up || wzm != uzm);
         if (!__ballot(changed)) break;
+        if (iters == 1) __builtin_amdgcn_s_setprio(2); // chain tails are the critical path: let them issue first
         if (changed) {
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
-            dc0 = dc1 = dc2 = 0;
-            decode_span<false, ReaderLds>(L, rowp, sp, slot_pack, nby, nb, p, z, m, end, nblk, dc0, dc1, dc2, nullptr, 0, flags);
+            decode_span<false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
@@ -303,10 +298,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
         r.u_p = up;
         r.u_zm = uzm;
         r.nblk = nblk;
-        r.dc[0] = (int16_t)dc0;
-        r.dc[1] = (int16_t)dc1;
-        r.dc[2] = (int16_t)dc2;
-        r.pad = 0;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
         P.sub[g] = r;
     }
     // diagnostics
@@ -331,7 +323,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     const HjdTableSet *ts = &P.tabs[im.tabset];
     load_tables(ts, s_lut, s_sec);
     const EntropyLds L = {s_lut, s_sec};
-    const uint32_t slot_pack = ts->slot_pack;
+    const uint32_t tabY = table_pair(ts->slot_pack, 0), tabCb = table_pair(ts->slot_pack, 1), tabCr = table_pair(ts->slot_pack, 2);
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
@@ -365,10 +357,9 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
         flags |= HJD_FLAG_NOT_CONVERGED; // induction step failed: host re-synchronises
     const HjdSubStart st = P.substart[g];
     uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
-    int dc0 = st.pred[0], dc1 = st.pred[1], dc2 = st.pred[2];
     if (!(flags & HJD_FLAG_NOT_CONVERGED))
-        decode_span<true, ReaderLds>(L, rowp, i * S, slot_pack, im.nby, im.nb, p, z, m, end, blk, dc0, dc1, dc2,
-                          P.coef + im.coef_off, im.nblocks, flags);
+        decode_span<true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
+                                     P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags);
     if (flags) atomicOr(&P.st[ii].flags, flags);
 }
 

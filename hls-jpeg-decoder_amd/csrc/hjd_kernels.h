@@ -15,6 +15,10 @@ struct HjdParams {
     HjdSub *sub;               // per subsequence
     HjdSubStart *substart;     // per subsequence
     int16_t *coef;             // dense coefficients
+    int16_t *dcd;              // DC differences, one per block (block index = coef_off/64 + b)
+    int16_t *dca;              // DC values after prediction
+    uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences
+    uint32_t ndcchunks;
     uint8_t *out;              // RGB / BMP bytes
     int nimg;
     uint32_t subseq_bits;      // power of two, 64..2048
@@ -29,5 +33,6 @@ struct HjdParams {
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int launch_idx, hipStream_t s);
 int hjd_launch_scan(const HjdParams &P, hipStream_t s);
+int hjd_launch_dcscan(const HjdParams &P, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

@@ -85,11 +85,14 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     // int16 wrap of the product as the reference's (short)(int) cast.
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(P.coef + im.coef_off + (size_t)b0 * 64);
+        const int16_t *dcabs = P.dca + im.coef_off / 64 + b0;
         const uint32_t n4 = KB * 8;
         for (uint32_t k = tid; k < n4; k += 256) {
-            const uint4 v = src[k];
-            if ((v.x | v.y | v.z | v.w) == 0u) continue;
+            uint4 v = src[k];
             const uint32_t blk = k >> 3, z0 = (k & 7) * 8;
+            if (z0 == 0u) // slot 0 of the row is unused: the predicted DC comes from k_dcscan
+                v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)dcabs[blk];
+            if ((v.x | v.y | v.z | v.w) == 0u) continue;
             const uint32_t mm = blk % nb;
             const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
             const uint32_t wd[4] = {v.x, v.y, v.z, v.w};

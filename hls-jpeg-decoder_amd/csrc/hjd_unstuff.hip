@@ -1,7 +1,8 @@
 // hjd_unstuff.hip — byte-level preparation of the scan and the prefix sums between the two
 // entropy passes (gfx950).
 //   k_unstuff_count / k_unstuff_write  bit-reader byte rule FF00 -> FF      (loadjpg.cpp:468-482)
-//   k_scan                             block index + DC predictor prefix     (loadjpg.cpp:619-667, :1159-1162)
+//   k_scan                             block index at every subsequence start
+//   k_dcsum / k_dcapply                DC prediction as a prefix sum          (loadjpg.cpp:619-667, :1159-1162)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -93,8 +94,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 }
 
 // ---- stage 2: prefix sums over subsequences ---------------------------------------------------
-// block index and DC predictors at every subsequence start; DC prediction runs over the whole
-// image and is never reset (loadjpg.cpp:1159-1162), all arithmetic mod 2^16 (loadjpg.cpp:664-665)
+// index of the block in progress at every subsequence start
 
 __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
 {
@@ -106,36 +106,98 @@ __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
     const uint32_t nsub = (total_bits + S - 1) / S;
     const uint32_t per = (nsub + blockDim.x - 1) / blockDim.x;
     const uint32_t lo = min(threadIdx.x * per, nsub), hi = min(lo + per, nsub);
-    uint32_t a = 0, b = 0, c = 0, d = 0;
-    for (uint32_t k = lo; k < hi; k++) {
-        const HjdSub r = P.sub[im.sub0 + k];
-        a += r.nblk;
-        b += (uint32_t)(int)r.dc[0];
-        c += (uint32_t)(int)r.dc[1];
-        d += (uint32_t)(int)r.dc[2];
-    }
-    uint32_t ta, tb, tc, td;
+    uint32_t a = 0;
+    for (uint32_t k = lo; k < hi; k++) a += P.sub[im.sub0 + k].nblk;
+    uint32_t ta;
     a = block_excl_scan(a, s_w, &ta);
-    b = block_excl_scan(b, s_w, &tb);
-    c = block_excl_scan(c, s_w, &tc);
-    d = block_excl_scan(d, s_w, &td);
     for (uint32_t k = lo; k < hi; k++) {
-        const HjdSub r = P.sub[im.sub0 + k];
-        HjdSubStart s;
-        s.blk0 = a;
-        s.pred[0] = (int16_t)b;
-        s.pred[1] = (int16_t)c;
-        s.pred[2] = (int16_t)d;
-        s.pad = 0;
-        P.substart[im.sub0 + k] = s;
-        a += r.nblk;
-        b += (uint32_t)(int)r.dc[0];
-        c += (uint32_t)(int)r.dc[1];
-        d += (uint32_t)(int)r.dc[2];
+        P.substart[im.sub0 + k].blk0 = a;
+        a += P.sub[im.sub0 + k].nblk;
     }
     if (threadIdx.x == 0) {
         P.st[ii].total_blocks = ta;
         if (ta < im.nblocks) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT);
+    }
+}
+
+// ---- stage 3b: DC prediction --------------------------------------------------------------------
+// DCT[0] = diff + previousDC per component, predictors zeroed once per image and never reset
+// (loadjpg.cpp:619-667, :1159-1162), int16 wrap (loadjpg.cpp:664-665) = prefix sums mod 2^16 over the
+// blocks of each component in decode order.  Two passes over chunks of HJD_DC_CHUNK MCUs:
+// k_dcsum (per-chunk totals), k_dcapply (totals of the earlier chunks + scan inside the chunk).
+
+#define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
+
+__device__ __forceinline__ void dc_thread_sums(const int16_t *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+                                               uint32_t &y, uint32_t &cb, uint32_t &cr)
+{
+    y = cb = cr = 0;
+    for (uint32_t mc = m0; mc < m1; mc++) {
+        const int16_t *q = d + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) y += (uint32_t)(int)q[k];
+        cb += (uint32_t)(int)q[nby];
+        cr += (uint32_t)(int)q[nby + 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
+{
+    __shared__ uint32_t s_w[17];
+    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.dcchunk0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t nmcu = im.mcux * im.mcuy;
+    const uint32_t c0 = (blockIdx.x - im.dcchunk0) * HJD_DC_CHUNK;
+    const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
+    uint32_t y, cb, cr, ty, tcb, tcr;
+    dc_thread_sums(P.dcd + im.coef_off / 64, m0, m1, im.nb, im.nby, y, cb, cr);
+    block_excl_scan(y, s_w, &ty);
+    block_excl_scan(cb, s_w, &tcb);
+    block_excl_scan(cr, s_w, &tcr);
+    if (threadIdx.x == 0) {
+        P.dcsum[blockIdx.x * 3 + 0] = ty;
+        P.dcsum[blockIdx.x * 3 + 1] = tcb;
+        P.dcsum[blockIdx.x * 3 + 2] = tcr;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
+{
+    __shared__ uint32_t s_w[17];
+    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.dcchunk0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t nb = im.nb, nby = im.nby;
+    const uint32_t nmcu = im.mcux * im.mcuy;
+    const uint32_t lc = blockIdx.x - im.dcchunk0;
+    // totals of this image's earlier chunks
+    uint32_t py = 0, pcb = 0, pcr = 0, t;
+    for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
+        py += P.dcsum[(im.dcchunk0 + k) * 3 + 0];
+        pcb += P.dcsum[(im.dcchunk0 + k) * 3 + 1];
+        pcr += P.dcsum[(im.dcchunk0 + k) * 3 + 2];
+    }
+    uint32_t by, bcb, bcr;
+    block_excl_scan(py, s_w, &by);
+    block_excl_scan(pcb, s_w, &bcb);
+    block_excl_scan(pcr, s_w, &bcr);
+    const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
+    const int16_t *d = P.dcd + im.coef_off / 64;
+    int16_t *o = P.dca + im.coef_off / 64;
+    uint32_t y, cb, cr;
+    dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
+    y = by + block_excl_scan(y, s_w, &t);
+    cb = bcb + block_excl_scan(cb, s_w, &t);
+    cr = bcr + block_excl_scan(cr, s_w, &t);
+    for (uint32_t mc = m0; mc < m1; mc++) {
+        const int16_t *q = d + (size_t)mc * nb;
+        int16_t *w = o + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) {
+            y += (uint32_t)(int)q[k];
+            w[k] = (int16_t)y;
+        }
+        cb += (uint32_t)(int)q[nby];
+        w[nby] = (int16_t)cb;
+        cr += (uint32_t)(int)q[nby + 1];
+        w[nby + 1] = (int16_t)cr;
     }
 }
 
@@ -159,6 +221,17 @@ int hjd_launch_scan(const HjdParams &P, hipStream_t s)
 {
     if (!P.nimg) return 0;
     hipLaunchKernelGGL(k_scan, dim3(P.nimg), dim3(1024), 0, s, P);
+    HJD_LAUNCH_CHECK();
+    return 0;
+}
+
+int hjd_launch_dcscan(const HjdParams &P, hipStream_t s)
+{
+    if (!P.nimg) return 0;
+    if (!P.ndcchunks) return 0;
+    hipLaunchKernelGGL(k_dcsum, dim3(P.ndcchunks), dim3(256), 0, s, P);
+    HJD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_dcapply, dim3(P.ndcchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }

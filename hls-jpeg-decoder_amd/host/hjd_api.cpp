@@ -44,7 +44,8 @@ struct hjd_batch {
     std::vector<size_t> hdr_bytes;
     std::vector<HjdImageState> state;
     int out_format = 0;
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
+    uint32_t *d_dcsum = nullptr;
     size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
     uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
     // device
@@ -55,7 +56,7 @@ struct hjd_batch {
     uint32_t *d_chunk_kept = nullptr;
     HjdSub *d_sub = nullptr;
     HjdSubStart *d_substart = nullptr;
-    int16_t *d_coef = nullptr;
+    int16_t *d_coef = nullptr, *d_dcd = nullptr, *d_dca = nullptr;
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -208,6 +209,9 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_sub);
     (void)hipFree(b->d_substart);
     (void)hipFree(b->d_coef);
+    (void)hipFree(b->d_dcd);
+    (void)hipFree(b->d_dca);
+    (void)hipFree(b->d_dcsum);
     if (b->have_events)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
@@ -282,6 +286,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.writewg0 = b->nwritewg;
         im.nwritewg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
         b->nwritewg += im.nwritewg;
+        im.dcchunk0 = b->ndcchunks;
+        im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
+        b->ndcchunks += im.ndcchunk;
         im.group0 = b->ngroups;
         im.groups_per_row = (im.mcux + HJD_GROUP_MCUS - 1) / HJD_GROUP_MCUS;
         im.ngroups = im.groups_per_row * im.mcuy;
@@ -342,6 +349,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_coef, sizeof(int16_t) * (coef_cur ? coef_cur : 1)));
+    HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (coef_cur / 64 + 1)));
+    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (coef_cur / 64 + 1)));
+    HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
+    HIPCHK(hipMemset(b->d_dcd, 0, sizeof(int16_t) * (coef_cur / 64 + 1)));
     HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
@@ -359,6 +370,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.sub = b->d_sub;
     P.substart = b->d_substart;
     P.coef = b->d_coef;
+    P.dcd = b->d_dcd;
+    P.dca = b->d_dca;
+    P.dcsum = b->d_dcsum;
+    P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
     P.subseq_bits = S;
@@ -448,6 +463,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     HIPCHK(hipMemsetAsync(b->d_coef, 0, sizeof(int16_t) * b->coef_elems, s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, b->nwritewg, s)) return HJD_ERR_INTERNAL;
+    if ((rc = mark("dc_scan"))) return rc;
+    if (hjd_launch_dcscan(P, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
     if (hjd_launch_idct_color(P, b->ngroups, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("end"))) return rc;
@@ -605,6 +622,10 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     const size_t ne = (size_t)b->img[di].nblocks * 64;
     if (elems < ne) return HJD_ERR_ARG;
     HIPCHK(hipMemcpy(dst, b->d_coef + b->img[di].coef_off, ne * 2, hipMemcpyDeviceToHost));
+    // the device keeps the predicted DC values in their own array (slot 0 of a row is unused)
+    std::vector<int16_t> dc(b->img[di].nblocks);
+    HIPCHK(hipMemcpy(dc.data(), b->d_dca + b->img[di].coef_off / 64, dc.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dc.size(); k++) dst[k * 64] = dc[k];
     return HJD_OK;
 }
 
