@@ -54,10 +54,12 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index u*8+v (u = horizontal frequency); +2 pad: bank spread
     __shared__ uint64_t s_mask[MAXGB];    // bit u*8+v set where the coefficient is non-zero
     __shared__ __attribute__((aligned(8))) uint8_t s_pix[MAXGB][72]; // decoded 8x8 tiles, row-major; +8 pad: bank spread
-    __shared__ float s_cosT[64];          // [u][x] = COS[x][u]
-    __shared__ float s_cos[64];           // [v][y] = COS[y][v]  (same matrix, named for its use)
+    __shared__ __attribute__((aligned(16))) float s_cosT[64]; // [u][x] = COS[x][u]
+    __shared__ __attribute__((aligned(16))) float s_cos[64];  // [v][y] = COS[y][v]  (same matrix, named for its use)
     __shared__ uint8_t s_qt[3][64];
     __shared__ uint8_t s_pos[64];
+    __shared__ uint8_t s_order[MAXGB];
+    __shared__ uint32_t s_hist[66];
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
@@ -115,15 +117,36 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
     __syncthreads();
 
-    // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Thread = (block, output column x),
-    // 8 row accumulators.  Terms are added in the reference's order (u outer, v inner); zero
-    // coefficients add +-0 and are skipped.  term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].
+    // Blocks are handed to the 4-lane teams in order of decreasing non-zero count, so that the sixteen
+    // teams of a wave run loops of similar length: counting sort over the 65 possible counts.
+    if (tid < 66) s_hist[tid] = 0;
+    __syncthreads();
+    uint32_t my_cnt = 0, my_slot = 0;
+    if (tid < KB) {
+        my_cnt = (uint32_t)__popcll((unsigned long long)s_mask[tid]);
+        my_slot = atomicAdd(&s_hist[64u - my_cnt], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive prefix over buckets 0..64 (bucket 64 = empty blocks, placed last)
+        const uint32_t h = s_hist[tid];
+        const uint32_t inc = wave_incl_scan(h);
+        s_hist[tid] = inc - h;
+        if (tid == 63) s_hist[64] = inc;
+    }
+    __syncthreads();
+    if (tid < KB) s_order[s_hist[64u - my_cnt] + my_slot] = (uint8_t)tid;
+    __syncthreads();
+
+    // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Thread = (block, two output columns
+    // x0, x0+1), 2 x 8 row accumulators.  Terms are added in the reference's order (u outer, v inner);
+    // zero coefficients add +-0 and are skipped.  term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].
     {
-        const uint32_t x = tid & 7;
-        for (uint32_t blk = tid >> 3; blk < KB; blk += 32) {
-            float acc[8];
+        const uint32_t x0 = (tid & 3) * 2;
+        for (uint32_t slot = tid >> 2; slot < KB; slot += 64) {
+            const uint32_t blk = s_order[slot];
+            float acc0[8], acc1[8];
 #pragma unroll
-            for (int y = 0; y < 8; y++) acc[y] = 0.0f;
+            for (int y = 0; y < 8; y++) acc0[y] = acc1[y] = 0.0f;
             uint64_t mk = s_mask[blk];
             while (mk) {
                 const uint32_t j = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
@@ -132,24 +155,23 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
                 // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1
                 const float kk = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
                 const float t1 = kk * (float)s_coef[blk][j];
-                const float t2 = t1 * s_cosT[u * 8 + x];
+                const float2 cx = *reinterpret_cast<const float2 *>(&s_cosT[u * 8 + x0]);
+                const float t2a = t1 * cx.x, t2b = t1 * cx.y;
                 const float4 ca = *reinterpret_cast<const float4 *>(&s_cos[v * 8]);
                 const float4 cb = *reinterpret_cast<const float4 *>(&s_cos[v * 8 + 4]);
-                acc[0] = acc[0] + t2 * ca.x;
-                acc[1] = acc[1] + t2 * ca.y;
-                acc[2] = acc[2] + t2 * ca.z;
-                acc[3] = acc[3] + t2 * ca.w;
-                acc[4] = acc[4] + t2 * cb.x;
-                acc[5] = acc[5] + t2 * cb.y;
-                acc[6] = acc[6] + t2 * cb.z;
-                acc[7] = acc[7] + t2 * cb.w;
+                const float cy[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    acc0[y] = acc0[y] + t2a * cy[y];
+                    acc1[y] = acc1[y] + t2b * cy[y];
+                }
             }
 #pragma unroll
             for (int y = 0; y < 8; y++) {
                 // (int)(0.25*sum) then short +128 then Clamp (loadjpg.cpp:123,136-137,219)
-                const int16_t t = (int16_t)(int)(acc[y] * 0.25f);
-                const int16_t lv = (int16_t)(t + 128);
-                s_pix[blk][y * 8 + x] = (uint8_t)clamp255(lv);
+                const int16_t ta = (int16_t)(int)(acc0[y] * 0.25f), tb = (int16_t)(int)(acc1[y] * 0.25f);
+                const uint32_t pa = clamp255((int16_t)(ta + 128)), pb = clamp255((int16_t)(tb + 128));
+                *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)(pa | (pb << 8));
             }
         }
     }
