@@ -116,6 +116,9 @@ def main():
 
     st = batch.finish(stream)
     assert all(s == 0 for s in st), st
+    if batch.resync_count() != 0:
+        raise SystemExit("bench: the timed steps needed a host-driven re-synchronisation (%d rounds): "
+                         "their outputs were not final inside the timed region" % batch.resync_count())
     stages, runs = batch.collect_timing()
 
     # parity of what was just timed: compare images of the batch with the CPU oracle (checker only)

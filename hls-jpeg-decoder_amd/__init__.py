@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
                                            ctypes.c_int, ip]
     L.hjd_batch_sync_stats.restype = ctypes.c_int
     L.hjd_batch_sync_stats.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    L.hjd_batch_resync_count.restype = ctypes.c_int
+    L.hjd_batch_resync_count.argtypes = [vp]
     L.hjd_decode_batch_host.restype = ctypes.c_int
     L.hjd_bmp_bytes.restype = sz
     L.hjd_bmp_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint]
@@ -223,6 +225,9 @@ class Batch:
         a = (ctypes.c_uint32 * 4)()
         lib().hjd_batch_sync_stats(self._h, i, a)
         return dict(iters=a[0], decodes=a[1], iters_max=a[2], nsub=a[3])
+
+    def resync_count(self):
+        return lib().hjd_batch_resync_count(self._h)
 
     def info(self, i):
         w, h = ctypes.c_uint(), ctypes.c_uint()

@@ -207,6 +207,25 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     const uint32_t own0 = wv * Q, own1 = own0 + Q;
     const uint32_t row0 = own0 >= K ? own0 - K : 0u;
 
+    const uint32_t S = P.subseq_bits;
+    const uint32_t total_bits = P.st[ii].ustream_len * 8u;
+    const uint32_t nsub = (total_bits + S - 1) / S;
+    const uint32_t i = row0 + lane;
+    const bool valid = i < nsub && i < own1;
+    const bool owned = valid && i >= own0;
+    const uint32_t g = im.sub0 + i;
+
+    if (mode != 0) {
+        // repair pass: nothing to do unless some record's start differs from its predecessor's end
+        bool need = false;
+        if (valid && i > 0) {
+            const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
+            const HjdSub r = P.sub[g];
+            need = pe.x != r.u_p || pe.y != r.u_zm;
+        }
+        if (!__syncthreads_or(need ? 1 : 0)) return;
+    }
+
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
     const HjdTableSet *ts = &P.tabs[im.tabset];
@@ -215,13 +234,6 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     const uint32_t tabY = table_pair(ts->slot_pack, 0), tabCb = table_pair(ts->slot_pack, 1), tabCr = table_pair(ts->slot_pack, 2);
     const uint32_t lw = P.log2_words;
 
-    const uint32_t S = P.subseq_bits;
-    const uint32_t total_bits = P.st[ii].ustream_len * 8u;
-    const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = row0 + lane;
-    const bool valid = i < nsub && i < own1;
-    const bool owned = valid && i >= own0;
-    const uint32_t g = im.sub0 + i;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, total_bits);
     const uint32_t nby = im.nby, nb = im.nb;

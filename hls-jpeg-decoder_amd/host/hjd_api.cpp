@@ -29,7 +29,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct hjd_decoder {
     int device = 0;
     uint32_t subseq_bits = 1024;
-    int sync_launches = 1;
+    int sync_launches = 2; // one synchronisation launch + one (normally empty) repair launch
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
 };
 
@@ -44,6 +44,7 @@ struct hjd_batch {
     std::vector<size_t> hdr_bytes;
     std::vector<HjdImageState> state;
     int out_format = 0;
+    int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
@@ -568,6 +569,7 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
                 break;
             }
             for (auto &st : b->state) st.flags = 0;
+            b->resyncs++;
             // keep ustream_len, clear flags
             std::vector<HjdImageState> tmp = b->state;
             HIPCHK(hipMemcpyAsync(b->d_st, tmp.data(), sizeof(HjdImageState) * b->nimg, hipMemcpyHostToDevice, s));
@@ -641,6 +643,8 @@ extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)
     (void)im;
     return HJD_OK;
 }
+
+extern "C" int hjd_batch_resync_count(const hjd_batch *b) { return b ? b->resyncs : -1; }
 
 extern "C" int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *alg, uint64_t *scan)
 {

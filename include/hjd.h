@@ -157,6 +157,9 @@ int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **sta
  * synchronisation workgroups, subsequence decodes executed while synchronising, max iterations of one
  * workgroup, number of subsequences}. */
 int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
+/* Number of host-driven re-synchronisation rounds hjd_batch_finish had to run since prepare
+ * (0 in normal operation: the in-stream repair launch already settled every state). */
+int hjd_batch_resync_count(const hjd_batch *b);
 
 /* Convenience: decode N host JPEGs to N caller-provided host buffers (RGB or BMP). */
 int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
