@@ -8,6 +8,8 @@
 //   substart : exclusive prefix sums over sub (first block index, DC predictors)
 //   coef     : dense int16 coefficients, zig-zag order, 64 per block (slot 0 unused: DC lives in dcd/dca)
 //   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
+//   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
+//              byte of every marker found inside the scan
 //   out      : RGB or BMP bytes
 #pragma once
 #include <stdint.h>
@@ -65,6 +67,10 @@ struct HjdImage {
     uint32_t ngroups;
     uint32_t out_stride;    // bytes per output row (3W, or BMP padded)
     uint32_t out_format;    // 0 RGB, 1 BMP
+    uint32_t restart;       // DRI seen: the reference's resync checks are live (loadjpg.cpp:535-550, :631-640)
+    uint32_t ri_blocks;     // blocks per restart interval (Ri * nb); 0 when Ri = 0
+    uint32_t mark_off;      // first entry of this image in the marker arrays
+    uint32_t mark_cap;      // entries reserved
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t coef_off;      // element offset into coef slab
@@ -80,12 +86,14 @@ struct HjdImageState {
     uint32_t sync_iters;    // diagnostics: sum over workgroups and launches of refinement iterations
     uint32_t sync_decodes;  // diagnostics: subsequence decodes executed by the synchronisation launches
     uint32_t sync_iters_max;
-    uint32_t pad[2];
+    uint32_t nmarkers;      // restart mode: markers (FF xx, xx != 0) found inside the scan
+    uint32_t pad;
 };
 #define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)
 #define HJD_FLAG_NOT_CONVERGED 4u // a subsequence was decoded from a stale start state
 #define HJD_FLAG_SHORT 8u         // stream ended before all blocks were decoded
+#define HJD_FLAG_DIRTY 16u        // restart stream outside the clean-resync domain
 
 // synchronisation record of one subsequence
 struct HjdSub {

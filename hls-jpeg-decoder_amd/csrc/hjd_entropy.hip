@@ -132,15 +132,36 @@ struct ReaderLds {
 // `rowp` points at word 0 of the lane's row (64 words between successive words), `row_bit0` is the
 // absolute bit position of the row's first bit.  tabY/tabCb/tabCr: byte offsets of the component's
 // (DC | AC << 16) primary tables.
-template <bool WRITE, class Reader>
+// RESTART (images with DRI): the reference resynchronises whenever its byte cursor sits on a marker
+// at a block start (loadjpg.cpp:535-550) — i.e. when a block ends inside the last data byte before
+// a marker — and between a DC code and its extra bits (loadjpg.cpp:631-640); DC predictors are NOT
+// reset.  Inside the clean-resync domain that equals: at the end of the last
+// block of an interval jump to the marker position; everything else the reference would do with a
+// marker (firing early on tiny trailing blocks, swallowing markers as data) is flagged DIRTY.
+// Speculative decodes are simply pulled back onto the next interval start when they run over a
+// marker, which also ends every synchronisation chain there.
+struct RestartCtx {
+    const uint32_t *mpos; // marker bit positions of the image
+    uint32_t nmark;
+    uint32_t mk;          // index of the next marker (first position > p at the start)
+    uint32_t ri_blocks;   // blocks per interval, 0 = no intervals expected
+    uint32_t left;        // WRITE: blocks left in the current interval
+};
+
+template <bool WRITE, bool RESTART, class Reader>
 __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
                                             uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
                                             uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
                                             int16_t *__restrict__ coef, int16_t *__restrict__ dcd, uint32_t nblocks,
-                                            uint32_t &flags)
+                                            uint32_t &flags, RestartCtx rc)
 {
     Reader rd;
     rd.init(rowp, p - row_bit0);
+    uint32_t mnext = 0xFFFFFFFFu;
+    if (RESTART) {
+        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
+        mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+    }
     uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
@@ -167,6 +188,8 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
             if (isdc) {
                 dcd[nblk] = (int16_t)val;
+                // the reference looks for a marker again between the DC code and its extra bits
+                if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
                 if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = (int16_t)val;
@@ -175,7 +198,8 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         }
         z += adv;
         tb = isdc ? pair >> 16 : tb;
-        if (z >= 64u) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
+        const bool blk_end = z >= 64u;
+        if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
             nblk++;
             m = (m + 1u == nb) ? 0u : m + 1u;
@@ -185,6 +209,28 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         const uint32_t tot = len + s;
         p += tot;
         rd.advance(tot);
+        if (RESTART) {
+            if (WRITE && blk_end) rc.left--;
+            if ((blk_end && p + 8u > mnext) || p > mnext) {
+                if (WRITE && nblk < nblocks) {
+                    // clean only if a whole interval of whole MCUs ends exactly here
+                    const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
+                    if (!clean) flags |= HJD_FLAG_DIRTY;
+                }
+                p = mnext;
+                z = 0u;
+                m = 0u;
+                pair = tabY;
+                tb = pair & 0xFFFFu;
+                rc.left = rc.ri_blocks;
+                rc.mk++;
+                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                rd.init(rowp, p - row_bit0);
+            } else if (WRITE && blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < nblocks) {
+                flags |= HJD_FLAG_DIRTY; // an interval ends here but the marker is not where the reference looks
+                rc.left = rc.ri_blocks;
+            }
+        }
     }
 }
 
@@ -250,13 +296,25 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
 
     uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
     uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the wave
+    RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
+    if (im.restart && valid) {
+        rc0.nmark = min(P.st[ii].nmarkers, im.mark_cap);
+        uint32_t lo = 0, hi = rc0.nmark; // first marker past the start of this row
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rc0.mpos[mid] <= sp) lo = mid + 1;
+            else hi = mid;
+        }
+        rc0.mk = lo;
+    }
     uint32_t ndec = 0;
     __syncthreads(); // tables are in LDS; from here on the waves run independently
 
     if (valid) {
         if (mode == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            decode_span<false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags);
+            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
+            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
             ep = p;
             ezm = z | (m << 8);
             ndec = 1;
@@ -294,7 +352,8 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
         if (changed) {
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
-            decode_span<false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags);
+            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
+            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
@@ -369,9 +428,25 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
         flags |= HJD_FLAG_NOT_CONVERGED; // induction step failed: host re-synchronises
     const HjdSubStart st = P.substart[g];
     uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
-    if (!(flags & HJD_FLAG_NOT_CONVERGED))
-        decode_span<true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                     P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags);
+    if (!(flags & HJD_FLAG_NOT_CONVERGED)) {
+        RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
+        if (im.restart) {
+            rc0.nmark = min(P.st[ii].nmarkers, im.mark_cap);
+            uint32_t lo = 0, hi = rc0.nmark;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rc0.mpos[mid] <= i * S) lo = mid + 1;
+                else hi = mid;
+            }
+            rc0.mk = lo;
+            rc0.left = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
+            decode_span<true, true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
+                                               P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0);
+        } else {
+            decode_span<true, false, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
+                                                P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0);
+        }
+    }
     if (flags) atomicOr(&P.st[ii].flags, flags);
 }
 

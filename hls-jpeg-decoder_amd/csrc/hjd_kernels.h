@@ -12,6 +12,9 @@ struct HjdParams {
     const uint8_t *raw;        // stuffed scans
     uint8_t *ustream;          // unstuffed scans, MSB-first words
     uint32_t *chunk_kept;      // kept bytes per unstuff chunk
+    uint32_t *chunk_mark;      // markers per unstuff chunk (restart mode)
+    uint32_t *mpos;            // marker bit positions
+    uint8_t *mval;             // marker codes
     HjdSub *sub;               // per subsequence
     HjdSubStart *substart;     // per subsequence
     int16_t *coef;             // dense coefficients

@@ -13,65 +13,98 @@
 // ---- stage 0: unstuff ------------------------------------------------------------------------
 // Bit-reader rule of FillNBits (loadjpg.cpp:468-482): the byte after a data 0xFF is dropped when
 // it is 0x00.  Here that is done once, data-parallel: 16 raw bytes per lane, 4 KiB per workgroup.
+// Without DRI, "FF xx" (xx != 0) is ordinary data for the reference's reader and stays in the stream.
+// With DRI the reference resynchronises on any FF xx it finds at a block start (loadjpg.cpp:535-550):
+// such pairs are taken OUT of the stream and their positions recorded (mark mask, bit j = the pair's
+// second byte), so that the entropy kernels can treat the intervals between them separately.
 
 __device__ __forceinline__ uint32_t unstuff_keepmask(const HjdImage &im, const uint8_t *raw, uint32_t lc,
-                                                      uint4 *vout, uint8_t *s_last)
+                                                      uint4 *vout, uint8_t *s_edge, uint32_t *markmask)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t off = lc * HJD_UNSTUFF_CHUNK + tid * 16;
     const uint8_t *base = raw + im.raw_off + off;
     uint4 v = *reinterpret_cast<const uint4 *>(base);
     *vout = v;
-    s_last[tid] = (uint8_t)(v.w >> 24);
+    s_edge[tid] = (uint8_t)(v.w >> 24);        // last byte, for the next lane
+    s_edge[256 + tid] = (uint8_t)(v.x & 0xFF); // first byte, for the previous lane
     __syncthreads();
-    uint32_t prev;
+    uint32_t prev, next;
     if (tid == 0) prev = (lc == 0) ? 0u : base[-1];
-    else prev = s_last[tid - 1];
+    else prev = s_edge[tid - 1];
+    if (tid == 255) next = base[16];
+    else next = s_edge[256 + tid + 1];
     int nvalid = (int)im.scan_len - (int)off;
     nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
+    if (nvalid < 16) next = 0; // the scan ends inside this lane
+    const bool rst = im.restart != 0;
     uint32_t words[4] = {v.x, v.y, v.z, v.w};
-    uint32_t mask = 0;
+    uint32_t mask = 0, marks = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFF;
-        bool keep = (j < nvalid) && !(b == 0 && prev == 0xFF);
+        const uint32_t b = (words[j >> 2] >> ((j & 3) * 8)) & 0xFF;
+        uint32_t nb = j < 15 ? (words[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFF : next;
+        if (j + 1 >= nvalid && nvalid < 16) nb = 0; // nothing follows the last byte of the scan
+        const bool inside = j < nvalid;
+        const bool second = prev == 0xFF; // the byte after an FF: a stuffing zero, or (restart mode) a marker code
+        bool keep;
+        if (rst) {
+            const bool mfirst = b == 0xFF && nb != 0; // FF that opens a marker pair
+            keep = inside && !second && !mfirst;
+            marks |= ((inside && second && b != 0) ? 1u : 0u) << j;
+            prev = second ? 0u : b; // a consumed pair never acts as "previous FF" (the reader restarts after it)
+        } else {
+            keep = inside && !(second && b == 0);
+            prev = b;
+        }
         mask |= (keep ? 1u : 0u) << j;
-        prev = b;
     }
+    *markmask = marks;
     return mask;
 }
 
 __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
 {
-    __shared__ uint8_t s_last[256];
+    __shared__ uint8_t s_edge[512];
     __shared__ uint32_t s_w[17];
     const uint32_t c = blockIdx.x;
     const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
     const HjdImage &im = P.img[ii];
     uint4 v;
-    uint32_t mask = unstuff_keepmask(im, P.raw, c - im.chunk0, &v, s_last);
-    uint32_t total;
+    uint32_t marks;
+    uint32_t mask = unstuff_keepmask(im, P.raw, c - im.chunk0, &v, s_edge, &marks);
+    uint32_t total, mtotal;
     block_excl_scan(__popc(mask), s_w, &total);
-    if (threadIdx.x == 0) P.chunk_kept[c] = total;
+    block_excl_scan(__popc(marks), s_w, &mtotal);
+    if (threadIdx.x == 0) {
+        P.chunk_kept[c] = total;
+        P.chunk_mark[c] = mtotal;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 {
-    __shared__ uint8_t s_last[256];
+    __shared__ uint8_t s_edge[512];
     __shared__ uint32_t s_w[17];
     const uint32_t c = blockIdx.x;
     const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
     const HjdImage &im = P.img[ii];
     const uint32_t lc = c - im.chunk0;
-    // kept bytes of this image's earlier chunks
-    uint32_t part = 0;
-    for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) part += P.chunk_kept[im.chunk0 + k];
-    uint32_t base;
+    // kept bytes and markers of this image's earlier chunks
+    uint32_t part = 0, mpart = 0;
+    for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
+        part += P.chunk_kept[im.chunk0 + k];
+        mpart += P.chunk_mark[im.chunk0 + k];
+    }
+    uint32_t base, mbase;
     block_excl_scan(part, s_w, &base);
+    block_excl_scan(mpart, s_w, &mbase);
     uint4 v;
-    uint32_t mask = unstuff_keepmask(im, P.raw, lc, &v, s_last);
-    uint32_t total;
+    uint32_t marks;
+    uint32_t mask = unstuff_keepmask(im, P.raw, lc, &v, s_edge, &marks);
+    uint32_t total, mtotal;
     uint32_t pos = base + block_excl_scan(__popc(mask), s_w, &total);
+    uint32_t mk = mbase + block_excl_scan(__popc(marks), s_w, &mtotal);
     // Transposed stream (see hjd_entropy.hip): word k of subsequence i -> ((i/64)*(wps+2) + k)*64 + i%64,
     // bytes MSB-first inside a word; words 0 and 1 of row i are repeated as words wps, wps+1 of row i-1.
     uint8_t *dst = P.ustream + im.ustream_off;
@@ -79,8 +112,18 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     uint32_t words[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 16; j++) {
+        const uint8_t bv = (uint8_t)(words[j >> 2] >> ((j & 3) * 8));
+        if (marks & (1u << j)) { // a marker sits between kept byte pos-1 and pos
+            if (mk < im.mark_cap) {
+                P.mpos[im.mark_off + mk] = pos * 8u;
+                P.mval[im.mark_off + mk] = bv;
+            }
+            // anything but RSTn / EOI inside the scan: the reference would take it for a resync point too,
+            // with results no standard stream defines
+            if (!((bv >= 0xD0 && bv <= 0xD7) || bv == 0xD9)) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
+            mk++;
+        }
         if (mask & (1u << j)) {
-            const uint8_t bv = (uint8_t)(words[j >> 2] >> ((j & 3) * 8));
             const uint32_t wq = pos >> 2, i = wq >> lw, k = wq & (wps - 1u), bsel = 3u - (pos & 3u);
             dst[(((size_t)(i >> 6) * (wps + 2u) + k) * 64u + (i & 63u)) * 4u + bsel] = bv;
             if (k < 2u && i >= 1u) {
@@ -90,7 +133,11 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
             pos++;
         }
     }
-    if (lc == im.nchunks - 1 && threadIdx.x == 0) P.st[ii].ustream_len = base + total;
+    if (lc == im.nchunks - 1 && threadIdx.x == 0) {
+        P.st[ii].ustream_len = base + total;
+        P.st[ii].nmarkers = mbase + mtotal;
+        if (mbase + mtotal > im.mark_cap) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
+    }
 }
 
 // ---- stage 2: prefix sums over subsequences ---------------------------------------------------

@@ -47,6 +47,9 @@ struct hjd_batch {
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
+    uint32_t nmarks = 0;
+    uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
+    uint8_t *d_mval = nullptr;
     size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
     uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
     // device
@@ -213,6 +216,9 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_dca);
     (void)hipFree(b->d_dcsum);
+    (void)hipFree(b->d_chunk_mark);
+    (void)hipFree(b->d_mpos);
+    (void)hipFree(b->d_mval);
     if (b->have_events)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
@@ -241,10 +247,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         b->dev_index[i] = -1;
         if (b->parse_status[i] != HJD_OK) continue;
         const hjd_jpeg_data &j = parsed[i];
-        if (j.restart_interval > 0) { // restart streams: handled by the interval path (not in this build)
-            b->parse_status[i] = HJD_ERR_UNSUPPORTED;
-            continue;
-        }
         if (j.stream_len >= (1u << 28)) {
             b->parse_status[i] = HJD_ERR_UNSUPPORTED;
             continue;
@@ -295,6 +297,11 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.ngroups = im.groups_per_row * im.mcuy;
         b->ngroups += im.ngroups;
         im.out_format = (uint32_t)b->out_format;
+        im.restart = j.restart_interval > 0 ? 1u : 0u; // the reference only tests "> 0" (loadjpg.cpp:535)
+        im.ri_blocks = im.restart ? j.restart_mcus * im.nb : 0u;
+        im.mark_off = b->nmarks;
+        im.mark_cap = im.restart ? (j.restart_mcus ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus : 0u) + 8u : 0u;
+        b->nmarks += im.mark_cap;
         size_t obytes;
         if (b->out_format == HJD_OUT_BMP) {
             im.out_stride = (im.width * 3 + 3) & ~3u;
@@ -347,6 +354,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_ustream, us_cur));
     HIPCHK(hipMalloc(&b->d_out, out_cur ? out_cur : 4));
     HIPCHK(hipMalloc(&b->d_chunk_kept, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
+    HIPCHK(hipMalloc(&b->d_chunk_mark, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
+    HIPCHK(hipMalloc(&b->d_mpos, sizeof(uint32_t) * (b->nmarks + 1)));
+    HIPCHK(hipMalloc(&b->d_mval, b->nmarks + 1));
     HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_coef, sizeof(int16_t) * (coef_cur ? coef_cur : 1)));
@@ -368,6 +378,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.raw = b->d_raw;
     P.ustream = b->d_ustream;
     P.chunk_kept = b->d_chunk_kept;
+    P.chunk_mark = b->d_chunk_mark;
+    P.mpos = b->d_mpos;
+    P.mval = b->d_mval;
     P.sub = b->d_sub;
     P.substart = b->d_substart;
     P.coef = b->d_coef;
@@ -584,6 +597,7 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
         if (st == HJD_OK && di >= 0) {
             const uint32_t f = b->state[di].flags;
             if (f & HJD_FLAG_NOT_CONVERGED) st = HJD_ERR_INTERNAL;
+            else if (f & HJD_FLAG_DIRTY) st = HJD_ERR_DIRTY_RESTART;
             else if (f & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN | HJD_FLAG_SHORT)) st = HJD_ERR_CORRUPT;
         }
         if (status) status[i] = st;

@@ -106,6 +106,59 @@ def test_subsequence_sizes(hjd, bits, golden):
     d.close()
 
 
+def test_restart_fixtures(hjd, dec, golden):
+    """Committed restart-marker fixtures: inside the clean-resync domain the output equals the compiled
+    reference's; the dirty one (reference fires early on tiny blocks) is refused."""
+    d, man = golden
+    fx = _ok_fixtures(golden, restart=("clean", "dirty"))
+    assert len(fx) >= 4
+    st, outs = dec.decode([f[2] for f in fx])
+    for (name, ent, data), s, o in zip(fx, st, outs):
+        if ent["restart"] == "dirty":
+            assert s == hjd.HJD_ERR_DIRTY_RESTART, (name, s)
+        else:
+            assert s == 0, (name, s)
+            assert hashlib.sha256(o.tobytes()).hexdigest() == ent["rgb_sha256"], name
+
+
+@pytest.mark.parametrize("w,h,hf,vf,rst,sigma", [
+    (640, 480, 2, 2, 40, 6.0),    # one MCU row per interval
+    (640, 480, 2, 2, 1, 6.0),     # every MCU its own interval
+    (333, 222, 1, 1, 7, 8.0),     # 4:4:4, ragged interval length
+    (500, 300, 2, 1, 3, 6.0),     # 4:2:2
+    (1920, 1080, 2, 2, 120, 6.0),
+    (256, 256, 2, 2, 5, 0.5),     # smooth content: tiny trailing blocks are likely
+    (256, 256, 1, 1, 1, 0.0),     # flat-ish 4:4:4, 1-MCU intervals: dirty in practice
+    (128, 128, 2, 2, 0xFFFF, 6.0),  # DRI present, interval longer than the image: no RSTn at all
+])
+def test_restart_synthetic_matches_oracle_or_is_refused(hjd, dec, w, h, hf, vf, rst, sigma):
+    """Mixed subsampling + restart intervals (BASELINE config 5).  The oracle emulates the reference's
+    resync rules exactly and reports whether the stream stays inside the clean-resync domain; the HIP
+    path must then be bit-exact, and outside it must refuse (never a silently different picture)."""
+    data = T.synth_jpeg(w, h, 77 + rst % 50, 85, hf, vf, rst, sigma)
+    orc, orgb, _, _, ost = T.oracle_decode(data)
+    st, outs = dec.decode([data])
+    if orc == 0 and ost.resyncs_dirty == 0:
+        assert st == [0], st
+        assert np.array_equal(outs[0], orgb)
+    else:
+        assert st[0] in (hjd.HJD_ERR_DIRTY_RESTART, hjd.HJD_ERR_CORRUPT), (st, ost.resyncs_dirty)
+
+
+def test_mixed_restart_batch(hjd, dec):
+    """Config 5 in one batch: 4:4:4 / 4:2:2 / 4:2:0, with and without DRI, different sizes."""
+    specs = [(320, 240, 1, 1, 0), (320, 240, 1, 1, 10), (400, 200, 2, 1, 0), (400, 200, 2, 1, 25),
+             (250, 187, 2, 2, 4), (512, 384, 2, 2, 0), (96, 80, 1, 2, 2)]
+    jpgs = [T.synth_jpeg(w, h, 300 + k, 85, hf, vf, rst, 7.0) for k, (w, h, hf, vf, rst) in enumerate(specs)]
+    st, outs = dec.decode(jpgs)
+    for j, s, o in zip(jpgs, st, outs):
+        orc, orgb, _, _, ost = T.oracle_decode(j)
+        if ost.resyncs_dirty == 0:
+            assert s == 0 and np.array_equal(o, orgb)
+        else:
+            assert s == hjd.HJD_ERR_DIRTY_RESTART
+
+
 def test_statuses(hjd, dec, golden):
     d, man = golden
     bad = [open(os.path.join(d, n), "rb").read() for n in ("pil_progressive.jpg", "pil_gray.jpg")]
