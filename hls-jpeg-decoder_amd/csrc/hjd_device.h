@@ -71,6 +71,7 @@ struct HjdImage {
     uint32_t ri_blocks;     // blocks per restart interval (Ri * nb); 0 when Ri = 0
     uint32_t mark_off;      // first entry of this image in the marker arrays
     uint32_t mark_cap;      // entries reserved
+    uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t coef_off;      // element offset into coef slab

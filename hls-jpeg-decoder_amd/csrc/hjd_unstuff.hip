@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
                 P.mpos[im.mark_off + mk] = pos * 8u;
                 P.mval[im.mark_off + mk] = bv;
             }
-            // anything but RSTn / EOI inside the scan: the reference would take it for a resync point too,
-            // with results no standard stream defines
-            if (!((bv >= 0xD0 && bv <= 0xD7) || bv == 0xD9)) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
+            // anything but RSTn between the intervals: the reference would take it for a resync point too,
+            // with results no standard stream defines (what follows the last interval — EOI, padding —
+            // is never looked at again)
+            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7)) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
             mk++;
         }
         if (mask & (1u << j)) {
@@ -136,7 +137,6 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     if (lc == im.nchunks - 1 && threadIdx.x == 0) {
         P.st[ii].ustream_len = base + total;
         P.st[ii].nmarkers = mbase + mtotal;
-        if (mbase + mtotal > im.mark_cap) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
     }
 }
 

@@ -302,6 +302,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.mark_off = b->nmarks;
         im.mark_cap = im.restart ? (j.restart_mcus ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus : 0u) + 8u : 0u;
         b->nmarks += im.mark_cap;
+        im.n_rst = (im.restart && j.restart_mcus) ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus - 1 : 0u;
         size_t obytes;
         if (b->out_format == HJD_OUT_BMP) {
             im.out_stride = (im.width * 3 + 3) & ~3u;
