@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images replicated to fill the batch")
     ap.add_argument("--subseq-bits", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,44 +91,65 @@ def main():
     jpgs = [distinct[i % len(distinct)] for i in range(args.batch)]
 
     dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits)
-    batch = dec.prepare(jpgs, hjd.OUT_RGB)  # parse + H2D: inputs are resident in HBM from here on
-    assert all(s == 0 for s in batch.parse_status), batch.parse_status
-    pixels, alg_bytes, scan_bytes = batch.totals()
-    stream = torch.cuda.current_stream().cuda_stream
+    # parse + H2D: inputs are resident in HBM from here on.  The per-GPU batch may be split into
+    # sub-batches that run on separate HIP streams, so that one sub-batch's latency-bound
+    # synchronisation tail overlaps another's IDCT (same total work per step).
+    ns = max(1, min(args.streams, args.batch))
+    parts = [jpgs[k::ns] for k in range(ns)]
+    batches = [dec.prepare(p, hjd.OUT_RGB) for p in parts]
+    for b in batches:
+        assert all(s == 0 for s in b.parse_status), b.parse_status
+    tot = [b.totals() for b in batches]
+    pixels, alg_bytes, scan_bytes = (sum(t[k] for t in tot) for k in range(3))
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    streams = [ts.cuda_stream for ts in tstreams]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.run(stream)
-    barrier()
-    st = batch.finish(stream)
-    assert all(s == 0 for s in st), st
+    def step():
+        for b, sh in zip(batches, streams):
+            b.run(sh)
 
-    batch.enable_timing(args.steps)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    for b, sh in zip(batches, streams):
+        st = b.finish(sh)
+        assert all(s == 0 for s in st), st
+
+    for b in batches:
+        b.enable_timing(args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run(stream)
+        step()
     barrier()
     dt = time.perf_counter() - t0
 
-    st = batch.finish(stream)
-    assert all(s == 0 for s in st), st
-    if batch.resync_count() != 0:
-        raise SystemExit("bench: the timed steps needed a host-driven re-synchronisation (%d rounds): "
-                         "their outputs were not final inside the timed region" % batch.resync_count())
-    stages, runs = batch.collect_timing()
+    stages_all = []
+    for b, sh in zip(batches, streams):
+        st = b.finish(sh)
+        assert all(s == 0 for s in st), st
+        if b.resync_count() != 0:
+            raise SystemExit("bench: the timed steps needed a host-driven re-synchronisation (%d rounds): "
+                             "their outputs were not final inside the timed region" % b.resync_count())
+        stg, runs = b.collect_timing()
+        stages_all.append(stg)
+    # per-launch stage durations: average over the sub-batches' launches (each launch covers 1/ns of the batch)
+    stages = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))]
+    launch_alg_bytes = alg_bytes / ns
 
     # parity of what was just timed: compare images of the batch with the CPU oracle (checker only)
     parity = "ok"
-    for i in sorted(set([0, len(jpgs) - 1])):
-        rc, orgb, _, _, _ = T.oracle_decode(jpgs[i])
-        got = batch.download(i)
+    for b, p in ((batches[0], parts[0]), (batches[-1], parts[-1])):
+        i = len(p) - 1
+        rc, orgb, _, _, _ = T.oracle_decode(p[i])
+        got = b.download(i)
         if rc != 0 or got.shape != orgb.shape or not (got == orgb).all():
-            parity = "MISMATCH image %d" % i
+            parity = "MISMATCH"
     if parity != "ok":
         raise SystemExit("bench: output differs from the oracle: " + parity)
 
@@ -142,7 +164,7 @@ def main():
         kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "scan": "k_scan",
                      "huff_write": "k_write", "idct_color": "k_idct_color", "coef_clear": "hipMemsetAsync",
                      "reset": "hipMemsetAsync"}
-        achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        achieved = launch_alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -174,7 +196,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(launch_alg_bytes),
+                         "launches_per_step": ns,
                          "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": stage_ms,
             "timed_runs": runs,
@@ -184,7 +207,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(jpgs, W, H)
         print(json.dumps(out), flush=True)
 
-    batch.close()
+    for b in batches:
+        b.close()
     dec.close()
     if world > 1:
         dist.destroy_process_group()
