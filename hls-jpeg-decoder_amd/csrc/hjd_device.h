@@ -6,7 +6,8 @@
 //              stored at address k^3), image i at ustream_off
 //   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
 //   substart : exclusive prefix sums over sub (first block index, DC predictors)
-//   coef     : dense int16 coefficients, zig-zag order, 64 per block (slot 0 unused: DC lives in dcd/dca)
+//   coef     : int16 coefficients, zig-zag order, 64 slots per block; NEVER cleared: only the slots named
+//              in bmask (one 64-bit word per block, cleared every run) are meaningful; slot 0 unused
 //   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan

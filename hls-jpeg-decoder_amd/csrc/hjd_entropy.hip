@@ -153,8 +153,14 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                                             uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
                                             uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
                                             int16_t *__restrict__ coef, int16_t *__restrict__ dcd, uint32_t nblocks,
-                                            uint32_t &flags, RestartCtx rc)
+                                            uint32_t &flags, RestartCtx rc, unsigned long long *__restrict__ bmask = nullptr)
 {
+    // WRITE: bit zz of `bm` = an AC coefficient was stored in zig-zag slot zz of the current block.  The
+    // coefficient slab is never cleared; the IDCT kernel reads only the slots these masks name.  A
+    // block decoded from its first to its last symbol by this lane stores its mask; blocks shared
+    // with a neighbouring lane are OR-ed into the (cleared) mask array.
+    unsigned long long bm = 0;
+    bool whole = z == 0u;
     Reader rd;
     rd.init(rowp, p - row_bit0);
     uint32_t mnext = 0xFFFFFFFFu;
@@ -192,14 +198,24 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
-                if (zw <= 63u) coef[(size_t)nblk * 64 + zw] = (int16_t)val;
-                else flags |= HJD_FLAG_OVERRUN;
+                if (zw <= 63u) {
+                    coef[(size_t)nblk * 64 + zw] = (int16_t)val;
+                    bm |= 1ull << zw;
+                } else {
+                    flags |= HJD_FLAG_OVERRUN;
+                }
             }
         }
         z += adv;
         tb = isdc ? pair >> 16 : tb;
         const bool blk_end = z >= 64u;
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
+            if (WRITE) {
+                if (whole) bmask[nblk] = bm;
+                else if (bm) atomicOr(&bmask[nblk], bm);
+                bm = 0;
+                whole = true;
+            }
             z = 0u;
             nblk++;
             m = (m + 1u == nb) ? 0u : m + 1u;
@@ -217,6 +233,11 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                     const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
                     if (!clean) flags |= HJD_FLAG_DIRTY;
                 }
+                if (WRITE && !blk_end && nblk < nblocks) { // dirty stream: a block cut short by a marker
+                    if (bm) atomicOr(&bmask[nblk], bm);
+                    bm = 0;
+                    whole = false;
+                }
                 p = mnext;
                 z = 0u;
                 m = 0u;
@@ -232,6 +253,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             }
         }
     }
+    if (WRITE && bm && nblk < nblocks) atomicOr(&bmask[nblk], bm); // block continues in the next subsequence
 }
 
 // ---- stage 1: synchronisation ----------------------------------------------------------------
@@ -441,10 +463,12 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
             rc0.mk = lo;
             rc0.left = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
             decode_span<true, true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                               P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0);
+                                               P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0,
+                                               P.bmask + im.coef_off / 64);
         } else {
             decode_span<true, false, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                                P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0);
+                                                P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0,
+                                               P.bmask + im.coef_off / 64);
         }
     }
     if (flags) atomicOr(&P.st[ii].flags, flags);

@@ -18,6 +18,7 @@ struct HjdParams {
     HjdSub *sub;               // per subsequence
     HjdSubStart *substart;     // per subsequence
     int16_t *coef;             // dense coefficients
+    unsigned long long *bmask; // per block: zig-zag slots of `coef` that hold a coefficient of this run
     int16_t *dcd;              // DC differences, one per block (block index = coef_off/64 + b)
     int16_t *dca;              // DC values after prediction
     uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences

@@ -81,20 +81,26 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     if (tid < MAXGB) s_mask[tid] = 0;
     __syncthreads();
 
-    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180).  The group's
-    // coefficient rows are contiguous: one coalesced 16-byte load (8 zig-zag slots) per thread and
-    // step; only non-zero values are scattered to their (u,v) slot and flagged in the block's mask.
-    // int16 wrap of the product as the reference's (short)(int) cast.
+    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180).  One thread per
+    // (block, 8 zig-zag slots): the block's slot mask (written by k_write) says which slots hold a
+    // coefficient — everything else in the never-cleared slab is stale — so 16-byte chunks without any
+    // are not even loaded.  Non-zero dequantised values are scattered to their (u,v) slot and flagged in
+    // the block's LDS mask.  int16 wrap of the product as the reference's (short)(int) cast.
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(P.coef + im.coef_off + (size_t)b0 * 64);
         const int16_t *dcabs = P.dca + im.coef_off / 64 + b0;
+        const unsigned long long *bmask = P.bmask + im.coef_off / 64 + b0;
         const uint32_t n4 = KB * 8;
         for (uint32_t k = tid; k < n4; k += 256) {
-            uint4 v = src[k];
             const uint32_t blk = k >> 3, z0 = (k & 7) * 8;
-            if (z0 == 0u) // slot 0 of the row is unused: the predicted DC comes from k_dcscan
+            uint32_t present = (uint32_t)(bmask[blk] >> z0) & 0xFFu;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (present) v = src[k];
+            if (z0 == 0u) { // slot 0 of the row is unused: the predicted DC comes from k_dcapply
                 v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)dcabs[blk];
-            if ((v.x | v.y | v.z | v.w) == 0u) continue;
+                present |= 1u;
+            }
+            if (!present) continue;
             const uint32_t mm = blk % nb;
             const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
             const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int c = (int)(int16_t)(wd[j >> 1] >> ((j & 1) * 16));
-                if (c != 0) {
+                if ((present >> j) & 1u) {
                     const uint32_t zz = z0 + j;
                     const int16_t nat = (int16_t)(c * (int)s_qt[comp][zz]);
                     if (nat != 0) {

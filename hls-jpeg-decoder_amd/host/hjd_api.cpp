@@ -61,6 +61,7 @@ struct hjd_batch {
     HjdSub *d_sub = nullptr;
     HjdSubStart *d_substart = nullptr;
     int16_t *d_coef = nullptr, *d_dcd = nullptr, *d_dca = nullptr;
+    unsigned long long *d_bmask = nullptr;
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -213,6 +214,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_sub);
     (void)hipFree(b->d_substart);
     (void)hipFree(b->d_coef);
+    (void)hipFree(b->d_bmask);
     (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_dca);
     (void)hipFree(b->d_dcsum);
@@ -361,6 +363,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_coef, sizeof(int16_t) * (coef_cur ? coef_cur : 1)));
+    HIPCHK(hipMalloc(&b->d_bmask, sizeof(unsigned long long) * (coef_cur / 64 + 1)));
     HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (coef_cur / 64 + 1)));
     HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (coef_cur / 64 + 1)));
     HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
@@ -385,6 +388,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.sub = b->d_sub;
     P.substart = b->d_substart;
     P.coef = b->d_coef;
+    P.bmask = b->d_bmask;
     P.dcd = b->d_dcd;
     P.dca = b->d_dca;
     P.dcsum = b->d_dcsum;
@@ -474,8 +478,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     }
     if ((rc = mark("scan"))) return rc;
     if (hjd_launch_scan(P, s)) return HJD_ERR_INTERNAL;
-    if ((rc = mark("coef_clear"))) return rc;
-    HIPCHK(hipMemsetAsync(b->d_coef, 0, sizeof(int16_t) * b->coef_elems, s));
+    if ((rc = mark("mask_clear"))) return rc;
+    HIPCHK(hipMemsetAsync(b->d_bmask, 0, sizeof(unsigned long long) * (b->coef_elems / 64), s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, b->nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
@@ -642,7 +646,13 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     // the device keeps the predicted DC values in their own array (slot 0 of a row is unused)
     std::vector<int16_t> dc(b->img[di].nblocks);
     HIPCHK(hipMemcpy(dc.data(), b->d_dca + b->img[di].coef_off / 64, dc.size() * 2, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < dc.size(); k++) dst[k * 64] = dc[k];
+    std::vector<unsigned long long> bm(b->img[di].nblocks);
+    HIPCHK(hipMemcpy(bm.data(), b->d_bmask + b->img[di].coef_off / 64, bm.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dc.size(); k++) {
+        for (int z = 1; z < 64; z++)
+            if (!((bm[k] >> z) & 1)) dst[k * 64 + z] = 0; // slots the mask does not name are stale
+        dst[k * 64] = dc[k];
+    }
     return HJD_OK;
 }
 
