@@ -60,13 +60,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images replicated to fill the batch")
     ap.add_argument("--subseq-bits", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams")
+    ap.add_argument("--streams", type=int, default=4, help="split the per-GPU batch over this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,7 +171,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(dom[0])
-                if ent and ent.get("batch") == args.batch and ent.get("width") == W and ent.get("height") == H:
+                if ent and ent.get("images_per_launch") * ns == args.batch and ent.get("width") == W and ent.get("height") == H:
                     traffic = ent["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
