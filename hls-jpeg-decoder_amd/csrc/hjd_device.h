@@ -6,8 +6,9 @@
 //              stored at address k^3), image i at ustream_off
 //   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
 //   substart : exclusive prefix sums over sub (first block index, DC predictors)
-//   coef     : int16 coefficients, zig-zag order, 64 slots per block; NEVER cleared: only the slots named
-//              in bmask (one 64-bit word per block, cleared every run) are meaningful; slot 0 unused
+//   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16; all ones =
+//              padding), every subsequence's run rounded up to 4 records so that it is written with
+//              aligned 16-byte stores; boff[b] = index of block b's first record (boff[nblocks] = end)
 //   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan
@@ -75,7 +76,11 @@ struct HjdImage {
     uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
-    uint64_t coef_off;      // element offset into coef slab
+    uint64_t blk_off;       // first entry of this image in the per-block arrays (dcd, dca)
+    uint64_t boff_off;      // first entry in boff (nblocks + 1 entries per image)
+    uint64_t rec_off;       // first record
+    uint32_t rec_cap;       // records reserved
+    uint32_t pad0;
     uint64_t out_off;       // byte offset into out slab
     uint8_t qt[3][64];      // dequantisation tables as USED per component (Cb already holds Cr's), zig-zag order
 };
@@ -104,9 +109,12 @@ struct HjdSub {
     uint32_t u_p;    // start state this record was computed from
     uint32_t u_zm;
     uint32_t nblk;   // blocks completed inside
-    uint32_t pad[3];
+    uint32_t nrec;   // AC records produced inside
+    uint32_t pad[2];
 };
 
 struct HjdSubStart {
     uint32_t blk0;   // index of the block in progress at the subsequence start
+    uint32_t rec0;   // index of the subsequence's first record (multiple of 4)
 };
+#define HJD_REC_PAD 0xFFFFFFFFu

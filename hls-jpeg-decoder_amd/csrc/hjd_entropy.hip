@@ -125,10 +125,12 @@ struct ReaderLds {
 };
 
 // Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
-//   WRITE = false: nblk counts blocks completed                                   (synchronisation)
-//   WRITE = true : nblk is the absolute block index; AC coefficients are stored in zig-zag order
-//                  (the DCT[] array of loadjpg.cpp:499-863), DC DIFFERENCES go to dcd[] — DC
-//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcscan
+//   WRITE = false: nblk counts blocks completed, nrec the AC records they hold      (synchronisation)
+//   WRITE = true : nblk is the absolute block index, nrec the index of the next record.  Every non-zero
+//                  AC coefficient becomes one record (value | zig-zag slot << 16: the DCT[] array of
+//                  loadjpg.cpp:499-863 in sparse form), appended to the lane's own run and stored four
+//                  at a time; boff[b] = first record of block b; DC DIFFERENCES go to dcd[] — DC
+//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcsum/k_dcapply
 // `rowp` points at word 0 of the lane's row (64 words between successive words), `row_bit0` is the
 // absolute bit position of the row's first bit.  tabY/tabCb/tabCr: byte offsets of the component's
 // (DC | AC << 16) primary tables.
@@ -152,15 +154,11 @@ template <bool WRITE, bool RESTART, class Reader>
 __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
                                             uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
                                             uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
-                                            int16_t *__restrict__ coef, int16_t *__restrict__ dcd, uint32_t nblocks,
-                                            uint32_t &flags, RestartCtx rc, unsigned long long *__restrict__ bmask = nullptr)
+                                            uint32_t &nrec, uint32_t *__restrict__ rec, uint32_t rec_cap,
+                                            uint32_t *__restrict__ boff, int16_t *__restrict__ dcd, uint32_t nblocks,
+                                            uint32_t &flags, RestartCtx rc)
 {
-    // WRITE: bit zz of `bm` = an AC coefficient was stored in zig-zag slot zz of the current block.  The
-    // coefficient slab is never cleared; the IDCT kernel reads only the slots these masks name.  A
-    // block decoded from its first to its last symbol by this lane stores its mask; blocks shared
-    // with a neighbouring lane are OR-ed into the (cleared) mask array.
-    unsigned long long bm = 0;
-    bool whole = z == 0u;
+    uint32_t q0 = HJD_REC_PAD, q1 = HJD_REC_PAD, q2 = HJD_REC_PAD; // WRITE: records waiting for their 16-byte store
     Reader rd;
     rd.init(rowp, p - row_bit0);
     uint32_t mnext = 0xFFFFFFFFu;
@@ -194,30 +192,36 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
             if (isdc) {
                 dcd[nblk] = (int16_t)val;
+                boff[nblk] = nrec;
                 // the reference looks for a marker again between the DC code and its extra bits
                 if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
-                if (zw <= 63u) {
-                    coef[(size_t)nblk * 64 + zw] = (int16_t)val;
-                    bm |= 1ull << zw;
-                } else {
+                uint32_t w = ((uint32_t)val & 0xFFFFu) | (zw << 16);
+                if (zw > 63u) {
                     flags |= HJD_FLAG_OVERRUN;
+                    w = HJD_REC_PAD;
                 }
+                const uint32_t k = nrec & 3u;
+                if (k == 3u) {
+                    if (nrec < rec_cap) *reinterpret_cast<uint4 *>(rec + (nrec - 3u)) = make_uint4(q0, q1, q2, w);
+                    else flags |= HJD_FLAG_OVERRUN;
+                }
+                q0 = k == 0u ? w : q0;
+                q1 = k == 1u ? w : q1;
+                q2 = k == 2u ? w : q2;
+                nrec++;
             }
+        } else if (!isdc && s != 0u) {
+            nrec++;
         }
         z += adv;
         tb = isdc ? pair >> 16 : tb;
         const bool blk_end = z >= 64u;
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
-            if (WRITE) {
-                if (whole) bmask[nblk] = bm;
-                else if (bm) atomicOr(&bmask[nblk], bm);
-                bm = 0;
-                whole = true;
-            }
             z = 0u;
             nblk++;
+            if (WRITE && nblk == nblocks) boff[nblk] = nrec; // end of the last block's records
             m = (m + 1u == nb) ? 0u : m + 1u;
             pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
             tb = pair & 0xFFFFu;
@@ -232,11 +236,6 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                     // clean only if a whole interval of whole MCUs ends exactly here
                     const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
                     if (!clean) flags |= HJD_FLAG_DIRTY;
-                }
-                if (WRITE && !blk_end && nblk < nblocks) { // dirty stream: a block cut short by a marker
-                    if (bm) atomicOr(&bmask[nblk], bm);
-                    bm = 0;
-                    whole = false;
                 }
                 p = mnext;
                 z = 0u;
@@ -253,7 +252,12 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             }
         }
     }
-    if (WRITE && bm && nblk < nblocks) atomicOr(&bmask[nblk], bm); // block continues in the next subsequence
+    if (WRITE && (nrec & 3u)) { // last, partial group of four: padded
+        const uint32_t k = nrec & 3u;
+        if (nrec + 4u - k <= rec_cap)
+            *reinterpret_cast<uint4 *>(rec + (nrec - k)) =
+                make_uint4(q0, k > 1u ? q1 : HJD_REC_PAD, k > 2u ? q2 : HJD_REC_PAD, HJD_REC_PAD);
+    }
 }
 
 // ---- stage 1: synchronisation ----------------------------------------------------------------
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     }
     const uint32_t *rowp = s_rows + lane;
 
-    uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, flags = 0;
+    uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, nrec = 0, flags = 0;
     uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the wave
     RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
     if (im.restart && valid) {
@@ -335,8 +339,8 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
     if (valid) {
         if (mode == 0) {
             uint32_t p = sp, z = 0, m = 0;
-            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
-            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
+            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
+            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
             ep = p;
             ezm = z | (m << 8);
             ndec = 1;
@@ -347,6 +351,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
             up = r.u_p;
             uzm = r.u_zm;
             nblk = r.nblk;
+            nrec = r.nrec;
             if (lane == 0 && i > 0) {
                 const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
                 if (pe.x >= sp && pe.x < sp + 32u) { // a record of this run always ends inside the next word
@@ -374,8 +379,9 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
         if (changed) {
             uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
             nblk = 0;
-            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
-            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nullptr, nullptr, 0, flags, rc0);
+            nrec = 0;
+            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
+            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
             ep = p;
             ezm = z | (m << 8);
             up = wp;
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P, int mode)
         r.u_p = up;
         r.u_zm = uzm;
         r.nblk = nblk;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        r.nrec = nrec;
+        r.pad[0] = r.pad[1] = 0;
         P.sub[g] = r;
     }
     // diagnostics
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     if (me.u_p != p || me.u_zm != zm || p < i * S || p >= i * S + 32u)
         flags |= HJD_FLAG_NOT_CONVERGED; // induction step failed: host re-synchronises
     const HjdSubStart st = P.substart[g];
-    uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0;
+    uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0, nrec = st.rec0;
     if (!(flags & HJD_FLAG_NOT_CONVERGED)) {
         RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
         if (im.restart) {
@@ -463,12 +470,12 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
             rc0.mk = lo;
             rc0.left = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
             decode_span<true, true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                               P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0,
-                                               P.bmask + im.coef_off / 64);
+                                               nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
+                                               P.dcd + im.blk_off, im.nblocks, flags, rc0);
         } else {
             decode_span<true, false, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                                P.coef + im.coef_off, P.dcd + im.coef_off / 64, im.nblocks, flags, rc0,
-                                               P.bmask + im.coef_off / 64);
+                                                nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
+                                                P.dcd + im.blk_off, im.nblocks, flags, rc0);
         }
     }
     if (flags) atomicOr(&P.st[ii].flags, flags);

@@ -17,9 +17,9 @@ struct HjdParams {
     uint8_t *mval;             // marker codes
     HjdSub *sub;               // per subsequence
     HjdSubStart *substart;     // per subsequence
-    int16_t *coef;             // dense coefficients
-    unsigned long long *bmask; // per block: zig-zag slots of `coef` that hold a coefficient of this run
-    int16_t *dcd;              // DC differences, one per block (block index = coef_off/64 + b)
+    uint32_t *rec;             // AC coefficient records
+    uint32_t *boff;            // per block: index of its first record
+    int16_t *dcd;              // DC differences, one per block (block index = blk_off + b)
     int16_t *dca;              // DC values after prediction
     uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences
     uint32_t ndcchunks;

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ uint8_t s_pos[64];
     __shared__ uint8_t s_order[MAXGB];
     __shared__ uint32_t s_hist[66];
+    __shared__ uint32_t s_boff[MAXGB + 1];
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
@@ -78,47 +79,44 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
     if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
     if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
-    if (tid < MAXGB) s_mask[tid] = 0;
     __syncthreads();
 
-    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180).  One thread per
-    // (block, 8 zig-zag slots): the block's slot mask (written by k_write) says which slots hold a
-    // coefficient — everything else in the never-cleared slab is stale — so 16-byte chunks without any
-    // are not even loaded.  Non-zero dequantised values are scattered to their (u,v) slot and flagged in
-    // the block's LDS mask.  int16 wrap of the product as the reference's (short)(int) cast.
+    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180) on the sparse form.
+    // The group's AC records are one contiguous range [boff[b0], boff[b0+KB]) of the record array
+    // (coalesced 4-byte loads); a record's block is found by bisecting the group's offsets in LDS.
+    // Non-zero dequantised values are scattered to their (u,v) slot and flagged in the block's LDS
+    // mask.  int16 wrap of the product as the reference's (short)(int) cast.
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.coef + im.coef_off + (size_t)b0 * 64);
-        const int16_t *dcabs = P.dca + im.coef_off / 64 + b0;
-        const unsigned long long *bmask = P.bmask + im.coef_off / 64 + b0;
-        const uint32_t n4 = KB * 8;
-        for (uint32_t k = tid; k < n4; k += 256) {
-            const uint32_t blk = k >> 3, z0 = (k & 7) * 8;
-            uint32_t present = (uint32_t)(bmask[blk] >> z0) & 0xFFu;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (present) v = src[k];
-            if (z0 == 0u) { // slot 0 of the row is unused: the predicted DC comes from k_dcapply
-                v.x = (v.x & 0xFFFF0000u) | (uint32_t)(uint16_t)dcabs[blk];
-                present |= 1u;
+        const uint32_t *rec = P.rec + im.rec_off;
+        const uint32_t *boff = P.boff + im.boff_off + b0;
+        if (tid <= KB) s_boff[tid] = min(boff[tid], im.rec_cap);
+        if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0
+            const uint32_t mm = tid % nb;
+            const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
+            const int16_t nat = (int16_t)((int)P.dca[im.blk_off + b0 + tid] * (int)s_qt[comp][0]);
+            s_coef[tid][0] = nat;
+            s_mask[tid] = nat != 0 ? 1ull : 0ull;
+        }
+        __syncthreads();
+        const uint32_t r0 = s_boff[0], r1 = s_boff[KB];
+        for (uint32_t t = r0 + tid; t < r1; t += 256) { // (a corrupt stream may leave r1 < r0: nothing to do)
+            const uint32_t w = rec[t];
+            if (w == HJD_REC_PAD) continue;
+            uint32_t lo = 0, hi = KB - 1; // last block whose first record is <= t
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (s_boff[mid] <= t) lo = mid;
+                else hi = mid - 1;
             }
-            if (!present) continue;
+            const uint32_t blk = lo, zz = (w >> 16) & 63u;
             const uint32_t mm = blk % nb;
             const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
-            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-            uint64_t mk = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int c = (int)(int16_t)(wd[j >> 1] >> ((j & 1) * 16));
-                if ((present >> j) & 1u) {
-                    const uint32_t zz = z0 + j;
-                    const int16_t nat = (int16_t)(c * (int)s_qt[comp][zz]);
-                    if (nat != 0) {
-                        const uint32_t pos = s_pos[zz];
-                        s_coef[blk][pos] = nat;
-                        mk |= 1ull << pos;
-                    }
-                }
+            const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
+            if (nat != 0) {
+                const uint32_t pos = s_pos[zz];
+                s_coef[blk][pos] = nat;
+                atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), 1ull << pos);
             }
-            if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), (unsigned long long)mk);
         }
     }
     __syncthreads();

@@ -1,7 +1,7 @@
 // hjd_unstuff.hip — byte-level preparation of the scan and the prefix sums between the two
 // entropy passes (gfx950).
 //   k_unstuff_count / k_unstuff_write  bit-reader byte rule FF00 -> FF      (loadjpg.cpp:468-482)
-//   k_scan                             block index at every subsequence start
+//   k_scan                             block and record index at every subsequence start
 //   k_dcsum / k_dcapply                DC prediction as a prefix sum          (loadjpg.cpp:619-667, :1159-1162)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 }
 
 // ---- stage 2: prefix sums over subsequences ---------------------------------------------------
-// index of the block in progress at every subsequence start
+// index of the block in progress and of the first record at every subsequence start
 
 __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
 {
@@ -153,13 +153,21 @@ __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
     const uint32_t nsub = (total_bits + S - 1) / S;
     const uint32_t per = (nsub + blockDim.x - 1) / blockDim.x;
     const uint32_t lo = min(threadIdx.x * per, nsub), hi = min(lo + per, nsub);
-    uint32_t a = 0;
-    for (uint32_t k = lo; k < hi; k++) a += P.sub[im.sub0 + k].nblk;
-    uint32_t ta;
-    a = block_excl_scan(a, s_w, &ta);
+    uint32_t a = 0, r = 0;
     for (uint32_t k = lo; k < hi; k++) {
-        P.substart[im.sub0 + k].blk0 = a;
         a += P.sub[im.sub0 + k].nblk;
+        r += (P.sub[im.sub0 + k].nrec + 3u) & ~3u; // every run is stored in whole groups of four records
+    }
+    uint32_t ta, tr;
+    a = block_excl_scan(a, s_w, &ta);
+    r = block_excl_scan(r, s_w, &tr);
+    for (uint32_t k = lo; k < hi; k++) {
+        HjdSubStart s;
+        s.blk0 = a;
+        s.rec0 = r;
+        P.substart[im.sub0 + k] = s;
+        a += P.sub[im.sub0 + k].nblk;
+        r += (P.sub[im.sub0 + k].nrec + 3u) & ~3u;
     }
     if (threadIdx.x == 0) {
         P.st[ii].total_blocks = ta;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
     const uint32_t c0 = (blockIdx.x - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     uint32_t y, cb, cr, ty, tcb, tcr;
-    dc_thread_sums(P.dcd + im.coef_off / 64, m0, m1, im.nb, im.nby, y, cb, cr);
+    dc_thread_sums(P.dcd + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
     block_excl_scan(y, s_w, &ty);
     block_excl_scan(cb, s_w, &tcb);
     block_excl_scan(cr, s_w, &tcr);
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     block_excl_scan(pcb, s_w, &bcb);
     block_excl_scan(pcr, s_w, &bcr);
     const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
-    const int16_t *d = P.dcd + im.coef_off / 64;
-    int16_t *o = P.dca + im.coef_off / 64;
+    const int16_t *d = P.dcd + im.blk_off;
+    int16_t *o = P.dca + im.blk_off;
     uint32_t y, cb, cr;
     dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
     y = by + block_excl_scan(y, s_w, &t);

@@ -50,7 +50,7 @@ struct hjd_batch {
     uint32_t nmarks = 0;
     uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
     uint8_t *d_mval = nullptr;
-    size_t raw_bytes = 0, ustream_bytes = 0, coef_elems = 0, out_total = 0;
+    size_t raw_bytes = 0, ustream_bytes = 0, nblocks_total = 0, nboff = 0, nrec = 0, out_total = 0;
     uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
     // device
     HjdImage *d_img = nullptr;
@@ -60,8 +60,8 @@ struct hjd_batch {
     uint32_t *d_chunk_kept = nullptr;
     HjdSub *d_sub = nullptr;
     HjdSubStart *d_substart = nullptr;
-    int16_t *d_coef = nullptr, *d_dcd = nullptr, *d_dca = nullptr;
-    unsigned long long *d_bmask = nullptr;
+    int16_t *d_dcd = nullptr, *d_dca = nullptr;
+    uint32_t *d_rec = nullptr, *d_boff = nullptr;
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -213,8 +213,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_chunk_kept);
     (void)hipFree(b->d_sub);
     (void)hipFree(b->d_substart);
-    (void)hipFree(b->d_coef);
-    (void)hipFree(b->d_bmask);
+    (void)hipFree(b->d_rec);
+    (void)hipFree(b->d_boff);
     (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_dca);
     (void)hipFree(b->d_dcsum);
@@ -241,7 +241,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     const uint32_t S = d->subseq_bits;
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
-    size_t raw_cur = 0, us_cur = 0, coef_cur = 0, out_cur = 0;
+    size_t raw_cur = 0, us_cur = 0, blk_cur = 0, boff_cur = 0, rec_cur = 0, out_cur = 0;
     uint32_t max_nlut = 1, max_nsec = 0;
     const uint32_t K = d->sync_overlap, Q = 64 - K; // per wave
 
@@ -321,8 +321,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
         im.ustream_off = us_cur;
         us_cur += ((size_t)im.nwritewg * (HJD_SYNC_WG / 64) + 2) * ((S / 32) + 2) * 256; // 64-row groups of wps+2 words, whole workgroups + slack for prefetch
-        im.coef_off = coef_cur;
-        coef_cur += (size_t)im.nblocks * 64;
+        im.blk_off = blk_cur;
+        blk_cur += im.nblocks;
+        im.boff_off = boff_cur;
+        boff_cur += (size_t)im.nblocks + 1;
+        {   // record capacity: one per non-zero AC coefficient (<= 63 per block, and every AC symbol with value
+            // bits takes at least 3 bits of scan), plus the rounding of every subsequence's run to 4
+            const uint64_t by_blocks = (uint64_t)im.nblocks * 63, by_bits = (uint64_t)im.scan_len * 8 / 3;
+            const uint64_t cap = (by_blocks < by_bits ? by_blocks : by_bits) + 4ull * im.nsub_cap + 64;
+            im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~3u;
+        }
+        im.rec_off = rec_cur;
+        rec_cur += im.rec_cap;
         // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
         memcpy(im.qt[0], j.qtable[1], 64);
         memcpy(im.qt[1], j.qtable[3], 64);
@@ -338,7 +348,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     b->nimg = (int)b->img.size();
     b->raw_bytes = raw_cur;
     b->ustream_bytes = us_cur;
-    b->coef_elems = coef_cur;
+    b->nblocks_total = blk_cur;
+    b->nboff = boff_cur;
+    b->nrec = rec_cur;
     b->out_total = out_cur;
     b->state.assign(b->nimg, HjdImageState{});
     if (!b->nimg) return HJD_OK;
@@ -362,12 +374,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_mval, b->nmarks + 1));
     HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMalloc(&b->d_coef, sizeof(int16_t) * (coef_cur ? coef_cur : 1)));
-    HIPCHK(hipMalloc(&b->d_bmask, sizeof(unsigned long long) * (coef_cur / 64 + 1)));
-    HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (coef_cur / 64 + 1)));
-    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (coef_cur / 64 + 1)));
+    HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + 4)));
+    HIPCHK(hipMalloc(&b->d_boff, sizeof(uint32_t) * (boff_cur + 1)));
+    HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (blk_cur + 1)));
+    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (blk_cur + 1)));
     HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
-    HIPCHK(hipMemset(b->d_dcd, 0, sizeof(int16_t) * (coef_cur / 64 + 1)));
+    HIPCHK(hipMemset(b->d_dcd, 0, sizeof(int16_t) * (blk_cur + 1)));
     HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
@@ -387,8 +399,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.mval = b->d_mval;
     P.sub = b->d_sub;
     P.substart = b->d_substart;
-    P.coef = b->d_coef;
-    P.bmask = b->d_bmask;
+    P.rec = b->d_rec;
+    P.boff = b->d_boff;
     P.dcd = b->d_dcd;
     P.dca = b->d_dca;
     P.dcsum = b->d_dcsum;
@@ -478,8 +490,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     }
     if ((rc = mark("scan"))) return rc;
     if (hjd_launch_scan(P, s)) return HJD_ERR_INTERNAL;
-    if ((rc = mark("mask_clear"))) return rc;
-    HIPCHK(hipMemsetAsync(b->d_bmask, 0, sizeof(unsigned long long) * (b->coef_elems / 64), s));
+    if ((rc = mark("boff_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
+    HIPCHK(hipMemsetAsync(b->d_boff, 0, sizeof(uint32_t) * b->nboff, s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, b->nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
@@ -640,18 +652,20 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     if (!b || !dst || i < 0 || i >= b->n) return HJD_ERR_ARG;
     const int di = b->dev_index[i];
     if (di < 0) return HJD_ERR_UNSUPPORTED;
-    const size_t ne = (size_t)b->img[di].nblocks * 64;
+    const HjdImage &im = b->img[di];
+    const size_t ne = (size_t)im.nblocks * 64;
     if (elems < ne) return HJD_ERR_ARG;
-    HIPCHK(hipMemcpy(dst, b->d_coef + b->img[di].coef_off, ne * 2, hipMemcpyDeviceToHost));
-    // the device keeps the predicted DC values in their own array (slot 0 of a row is unused)
-    std::vector<int16_t> dc(b->img[di].nblocks);
-    HIPCHK(hipMemcpy(dc.data(), b->d_dca + b->img[di].coef_off / 64, dc.size() * 2, hipMemcpyDeviceToHost));
-    std::vector<unsigned long long> bm(b->img[di].nblocks);
-    HIPCHK(hipMemcpy(bm.data(), b->d_bmask + b->img[di].coef_off / 64, bm.size() * 8, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < dc.size(); k++) {
-        for (int z = 1; z < 64; z++)
-            if (!((bm[k] >> z) & 1)) dst[k * 64 + z] = 0; // slots the mask does not name are stale
-        dst[k * 64] = dc[k];
+    // test hook: rebuild the dense DCT[] rows from the device's sparse form (records + offsets + predicted DC)
+    std::vector<uint32_t> boff(im.nblocks + 1), rec(im.rec_cap);
+    std::vector<int16_t> dc(im.nblocks);
+    HIPCHK(hipMemcpy(boff.data(), b->d_boff + im.boff_off, boff.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rec.data(), b->d_rec + im.rec_off, rec.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dc.data(), b->d_dca + im.blk_off, dc.size() * 2, hipMemcpyDeviceToHost));
+    memset(dst, 0, ne * 2);
+    for (uint32_t k = 0; k < im.nblocks; k++) {
+        dst[(size_t)k * 64] = dc[k];
+        for (uint32_t t = boff[k]; t < boff[k + 1] && t < im.rec_cap; t++)
+            if (rec[t] != HJD_REC_PAD) dst[(size_t)k * 64 + ((rec[t] >> 16) & 63)] = (int16_t)(rec[t] & 0xFFFF);
     }
     return HJD_OK;
 }
