@@ -20,7 +20,7 @@
 #define HJD_LUT_SIZE (1 << HJD_LUT_BITS)
 #define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
-#define HJD_SYNC_WG 512        // threads (= subsequences) per entropy workgroup: 8 independent waves sharing the tables
+#define HJD_SYNC_WG 256        // threads (= subsequences) per entropy workgroup: 4 independent waves sharing the tables
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 1024      // MCUs per DC-prediction workgroup
 
