@@ -7,8 +7,8 @@
 //   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
 //   substart : exclusive prefix sums over sub (first block index, DC predictors)
 //   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16; all ones =
-//              padding), every subsequence's run rounded up to 4 records so that it is written with
-//              aligned 16-byte stores; boff[b] = index of block b's first record (boff[nblocks] = end)
+//              padding), every subsequence's run rounded up to HJD_REC_RUN records so that it is
+//              written in aligned bursts; boff[b] = index of block b's first record (boff[nblocks] = end)
 //   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan
@@ -115,6 +115,7 @@ struct HjdSub {
 
 struct HjdSubStart {
     uint32_t blk0;   // index of the block in progress at the subsequence start
-    uint32_t rec0;   // index of the subsequence's first record (multiple of 4)
+    uint32_t rec0;   // index of the subsequence's first record (multiple of HJD_REC_RUN)
 };
 #define HJD_REC_PAD 0xFFFFFFFFu
+#define HJD_REC_RUN 16 // records per aligned store burst: every subsequence's run is padded to a multiple

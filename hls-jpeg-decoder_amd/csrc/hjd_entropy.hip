@@ -156,9 +156,11 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                                             uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
                                             uint32_t &nrec, uint32_t *__restrict__ rec, uint32_t rec_cap,
                                             uint32_t *__restrict__ boff, int16_t *__restrict__ dcd, uint32_t nblocks,
-                                            uint32_t &flags, RestartCtx rc)
+                                            uint32_t &flags, RestartCtx rc, uint32_t *s_rbuf = nullptr)
 {
-    uint32_t q0 = HJD_REC_PAD, q1 = HJD_REC_PAD, q2 = HJD_REC_PAD; // WRITE: records waiting for their 16-byte store
+    // WRITE: s_rbuf[k * HJD_SYNC_WG] (k < HJD_REC_RUN) = this lane's records waiting for their store burst.
+    // A full burst leaves as back-to-back 16-byte stores to one aligned 32-byte piece of the record
+    // array, so that the memory side sees whole sectors instead of a trickle of partial ones.
     Reader rd;
     rd.init(rowp, p - row_bit0);
     uint32_t mnext = 0xFFFFFFFFu;
@@ -202,14 +204,19 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                     flags |= HJD_FLAG_OVERRUN;
                     w = HJD_REC_PAD;
                 }
-                const uint32_t k = nrec & 3u;
-                if (k == 3u) {
-                    if (nrec < rec_cap) *reinterpret_cast<uint4 *>(rec + (nrec - 3u)) = make_uint4(q0, q1, q2, w);
-                    else flags |= HJD_FLAG_OVERRUN;
+                const uint32_t k = nrec & (HJD_REC_RUN - 1u);
+                s_rbuf[k * HJD_SYNC_WG] = w;
+                if (k == HJD_REC_RUN - 1u) {
+                    if (nrec < rec_cap) {
+                        uint4 *dst = reinterpret_cast<uint4 *>(rec + (nrec - (HJD_REC_RUN - 1u)));
+#pragma unroll
+                        for (int g = 0; g < HJD_REC_RUN / 4; g++)
+                            dst[g] = make_uint4(s_rbuf[(4 * g) * HJD_SYNC_WG], s_rbuf[(4 * g + 1) * HJD_SYNC_WG],
+                                                s_rbuf[(4 * g + 2) * HJD_SYNC_WG], s_rbuf[(4 * g + 3) * HJD_SYNC_WG]);
+                    } else {
+                        flags |= HJD_FLAG_OVERRUN;
+                    }
                 }
-                q0 = k == 0u ? w : q0;
-                q1 = k == 1u ? w : q1;
-                q2 = k == 2u ? w : q2;
                 nrec++;
             }
         } else if (!isdc && s != 0u) {
@@ -252,11 +259,18 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             }
         }
     }
-    if (WRITE && (nrec & 3u)) { // last, partial group of four: padded
-        const uint32_t k = nrec & 3u;
-        if (nrec + 4u - k <= rec_cap)
-            *reinterpret_cast<uint4 *>(rec + (nrec - k)) =
-                make_uint4(q0, k > 1u ? q1 : HJD_REC_PAD, k > 2u ? q2 : HJD_REC_PAD, HJD_REC_PAD);
+    if (WRITE && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: padded
+        const uint32_t k = nrec & (HJD_REC_RUN - 1u);
+        if (nrec + HJD_REC_RUN - k <= rec_cap) {
+            uint4 *dst = reinterpret_cast<uint4 *>(rec + (nrec - k));
+#pragma unroll
+            for (int g = 0; g < HJD_REC_RUN / 4; g++) {
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (uint32_t)(4 * g + j) < k ? s_rbuf[(4 * g + j) * HJD_SYNC_WG] : HJD_REC_PAD;
+                dst[g] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        }
     }
 }
 
@@ -433,6 +447,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t rowwords = ((1u << P.log2_words) + 2u) * 64u;
     uint32_t *s_rows = s_dyn + P.lds_stream_word + wv * rowwords;
+    uint32_t *s_rbuf = s_dyn + P.lds_stream_word + (HJD_SYNC_WG / 64) * rowwords + threadIdx.x;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(
             row_base(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), i & ~63u, P.log2_words));
@@ -471,11 +486,11 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
             rc0.left = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
             decode_span<true, true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
                                                nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
-                                               P.dcd + im.blk_off, im.nblocks, flags, rc0);
+                                               P.dcd + im.blk_off, im.nblocks, flags, rc0, s_rbuf);
         } else {
             decode_span<true, false, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
                                                 nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
-                                                P.dcd + im.blk_off, im.nblocks, flags, rc0);
+                                                P.dcd + im.blk_off, im.nblocks, flags, rc0, s_rbuf);
         }
     }
     if (flags) atomicOr(&P.st[ii].flags, flags);
@@ -503,8 +518,9 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
 {
     if (!nwg) return 0;
-    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), P.lds_bytes)) return -1;
-    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P);
+    const uint32_t lds = P.lds_bytes + HJD_REC_RUN * HJD_SYNC_WG * 4; // + the record bursts in waiting
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), lds)) return -1;
+    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
     uint32_t a = 0, r = 0;
     for (uint32_t k = lo; k < hi; k++) {
         a += P.sub[im.sub0 + k].nblk;
-        r += (P.sub[im.sub0 + k].nrec + 3u) & ~3u; // every run is stored in whole groups of four records
+        r += (P.sub[im.sub0 + k].nrec + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u); // every run is stored in whole bursts
     }
     uint32_t ta, tr;
     a = block_excl_scan(a, s_w, &ta);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
         s.rec0 = r;
         P.substart[im.sub0 + k] = s;
         a += P.sub[im.sub0 + k].nblk;
-        r += (P.sub[im.sub0 + k].nrec + 3u) & ~3u;
+        r += (P.sub[im.sub0 + k].nrec + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
     }
     if (threadIdx.x == 0) {
         P.st[ii].total_blocks = ta;

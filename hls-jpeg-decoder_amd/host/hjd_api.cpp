@@ -328,8 +328,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         {   // record capacity: one per non-zero AC coefficient (<= 63 per block, and every AC symbol with value
             // bits takes at least 3 bits of scan), plus the rounding of every subsequence's run to 4
             const uint64_t by_blocks = (uint64_t)im.nblocks * 63, by_bits = (uint64_t)im.scan_len * 8 / 3;
-            const uint64_t cap = (by_blocks < by_bits ? by_blocks : by_bits) + 4ull * im.nsub_cap + 64;
-            im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~3u;
+            const uint64_t cap = (by_blocks < by_bits ? by_blocks : by_bits) + (uint64_t)HJD_REC_RUN * im.nsub_cap + 64;
+            im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~(uint32_t)(HJD_REC_RUN - 1);
         }
         im.rec_off = rec_cur;
         rec_cur += im.rec_cap;
@@ -374,7 +374,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_mval, b->nmarks + 1));
     HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + 4)));
+    HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     HIPCHK(hipMalloc(&b->d_boff, sizeof(uint32_t) * (boff_cur + 1)));
     HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (blk_cur + 1)));
     HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (blk_cur + 1)));
