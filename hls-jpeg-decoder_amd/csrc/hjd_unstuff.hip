@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
 __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 {
     __shared__ uint8_t s_edge[512];
+    __shared__ __attribute__((aligned(4))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 8];
     __shared__ uint32_t s_w[17];
     const uint32_t c = blockIdx.x;
     const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
@@ -107,8 +108,24 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     uint32_t mk = mbase + block_excl_scan(__popc(marks), s_w, &mtotal);
     // Transposed stream (see hjd_entropy.hip): word k of subsequence i -> ((i/64)*(wps+2) + k)*64 + i%64,
     // bytes MSB-first inside a word; words 0 and 1 of row i are repeated as words wps, wps+1 of row i-1.
+    // The chunk's kept bytes are first compacted in LDS (byte index ^ 3, so that a 32-bit read yields the
+    // MSB-first word); whole words then go out as 4-byte stores, the up to three bytes of the partial
+    // words at either end of the chunk (shared with the neighbouring chunks) as byte stores.
     uint8_t *dst = P.ustream + im.ustream_off;
     const uint32_t lw = P.log2_words, wps = 1u << lw;
+    const uint32_t wbase = base & ~3u; // stream position of LDS byte 0
+    auto put_word_or_byte = [&](uint32_t wq, uint32_t value, int bsel) {
+        const uint32_t i = wq >> lw, k = wq & (wps - 1u);
+        const size_t a0 = (((size_t)(i >> 6) * (wps + 2u) + k) * 64u + (i & 63u)) * 4u;
+        if (bsel < 0) *reinterpret_cast<uint32_t *>(dst + a0) = value;
+        else dst[a0 + (uint32_t)bsel] = (uint8_t)value;
+        if (k < 2u && i >= 1u) {
+            const uint32_t i1 = i - 1u;
+            const size_t a1 = (((size_t)(i1 >> 6) * (wps + 2u) + wps + k) * 64u + (i1 & 63u)) * 4u;
+            if (bsel < 0) *reinterpret_cast<uint32_t *>(dst + a1) = value;
+            else dst[a1 + (uint32_t)bsel] = (uint8_t)value;
+        }
+    };
     uint32_t words[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -125,13 +142,23 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
             mk++;
         }
         if (mask & (1u << j)) {
-            const uint32_t wq = pos >> 2, i = wq >> lw, k = wq & (wps - 1u), bsel = 3u - (pos & 3u);
-            dst[(((size_t)(i >> 6) * (wps + 2u) + k) * 64u + (i & 63u)) * 4u + bsel] = bv;
-            if (k < 2u && i >= 1u) {
-                const uint32_t i1 = i - 1u;
-                dst[(((size_t)(i1 >> 6) * (wps + 2u) + wps + k) * 64u + (i1 & 63u)) * 4u + bsel] = bv;
-            }
+            s_bytes[(pos - wbase) ^ 3u] = bv;
             pos++;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t endp = base + total;                 // one past the chunk's last kept byte
+        const uint32_t w_first = (base + 3u) >> 2, w_last = endp >> 2; // whole words [w_first, w_last)
+        for (uint32_t wq = w_first + threadIdx.x; wq < w_last; wq += blockDim.x)
+            put_word_or_byte(wq, *reinterpret_cast<const uint32_t *>(&s_bytes[(wq << 2) - wbase]), -1);
+        // bytes of the partial words: head = [base, min(4*w_first, endp)), tail = [4*w_last, endp) when w_last >= w_first
+        if (threadIdx.x < 4) {
+            const uint32_t q = base + threadIdx.x;
+            if (q < min(w_first << 2, endp)) put_word_or_byte(q >> 2, s_bytes[(q - wbase) ^ 3u], (int)(3u - (q & 3u)));
+        } else if (threadIdx.x < 8 && w_last >= w_first) {
+            const uint32_t q = (w_last << 2) + (threadIdx.x - 4);
+            if (q < endp) put_word_or_byte(q >> 2, s_bytes[(q - wbase) ^ 3u], (int)(3u - (q & 3u)));
         }
     }
     if (lc == im.nchunks - 1 && threadIdx.x == 0) {
