@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ __attribute__((aligned(16))) float s_cos[64];  // [v][y] = COS[y][v]  (same matrix, named for its use)
     __shared__ uint8_t s_qt[3][64];
     __shared__ uint8_t s_pos[64];
+    __shared__ float s_kk[64];            // C(u)*C(v) by index u*8+v
     __shared__ uint8_t s_order[MAXGB];
     __shared__ uint32_t s_hist[66];
     __shared__ uint32_t s_boff[MAXGB + 1];
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
     if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
     if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
+    if (tid < 64) { // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
+        const uint32_t u = tid >> 3, v = tid & 7;
+        s_kk[tid] = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
+    }
     __syncthreads();
 
     // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180) on the sparse form.
@@ -151,23 +156,25 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             float acc0[8], acc1[8];
 #pragma unroll
             for (int y = 0; y < 8; y++) acc0[y] = acc1[y] = 0.0f;
-            uint64_t mk = s_mask[blk];
-            while (mk) {
-                const uint32_t j = (uint32_t)__ffsll((unsigned long long)mk) - 1u;
-                mk &= mk - 1;
-                const uint32_t u = j >> 3, v = j & 7;
-                // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1
-                const float kk = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
-                const float t1 = kk * (float)s_coef[blk][j];
-                const float2 cx = *reinterpret_cast<const float2 *>(&s_cosT[u * 8 + x0]);
-                const float t2a = t1 * cx.x, t2b = t1 * cx.y;
-                const float4 ca = *reinterpret_cast<const float4 *>(&s_cos[v * 8]);
-                const float4 cb = *reinterpret_cast<const float4 *>(&s_cos[v * 8 + 4]);
-                const float cy[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            const uint64_t mk = s_mask[blk];
 #pragma unroll
-                for (int y = 0; y < 8; y++) {
-                    acc0[y] = acc0[y] + t2a * cy[y];
-                    acc1[y] = acc1[y] + t2b * cy[y];
+            for (int half = 0; half < 2; half++) { // u = 0..3, then u = 4..7: ascending set bits = the term order
+                uint32_t m32 = half ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                while (m32) {
+                    const uint32_t j = half * 32u + (uint32_t)__ffs((int)m32) - 1u;
+                    m32 &= m32 - 1u;
+                    const uint32_t u = j >> 3, v = j & 7;
+                    const float t1 = s_kk[j] * (float)s_coef[blk][j];
+                    const float2 cx = *reinterpret_cast<const float2 *>(&s_cosT[u * 8 + x0]);
+                    const float t2a = t1 * cx.x, t2b = t1 * cx.y;
+                    const float4 ca = *reinterpret_cast<const float4 *>(&s_cos[v * 8]);
+                    const float4 cb = *reinterpret_cast<const float4 *>(&s_cos[v * 8 + 4]);
+                    const float cy[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                    for (int y = 0; y < 8; y++) {
+                        acc0[y] = acc0[y] + t2a * cy[y];
+                        acc1[y] = acc1[y] + t2b * cy[y];
+                    }
                 }
             }
 #pragma unroll
