@@ -87,8 +87,6 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __syncthreads();
 
     // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180) on the sparse form.
-    // The group's AC records are one contiguous range [boff[b0], boff[b0+KB]) of the record array
-    // (coalesced 4-byte loads); a record's block is found by bisecting the group's offsets in LDS.
     // Non-zero dequantised values are scattered to their (u,v) slot and flagged in the block's LDS
     // mask.  int16 wrap of the product as the reference's (short)(int) cast.
     {
@@ -103,25 +101,25 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             s_mask[tid] = nat != 0 ? 1ull : 0ull;
         }
         __syncthreads();
-        const uint32_t r0 = s_boff[0], r1 = s_boff[KB];
-        for (uint32_t t = r0 + tid; t < r1; t += 256) { // (a corrupt stream may leave r1 < r0: nothing to do)
-            const uint32_t w = rec[t];
-            if (w == HJD_REC_PAD) continue;
-            uint32_t lo = 0, hi = KB - 1; // last block whose first record is <= t
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (s_boff[mid] <= t) lo = mid;
-                else hi = mid - 1;
-            }
-            const uint32_t blk = lo, zz = (w >> 16) & 63u;
+        // sixteen threads per block walk its record range [boff[b], boff[b+1]) (contiguous, so the team's
+        // loads coalesce); r1 < r0 after a corrupt stream simply yields no work
+        for (uint32_t blk = tid >> 4; blk < KB; blk += 16) {
+            const uint32_t r0 = s_boff[blk], r1 = s_boff[blk + 1];
             const uint32_t mm = blk % nb;
             const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
-            const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
-            if (nat != 0) {
-                const uint32_t pos = s_pos[zz];
-                s_coef[blk][pos] = nat;
-                atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), 1ull << pos);
+            unsigned long long mk = 0;
+            for (uint32_t t = r0 + (tid & 15u); t < r1; t += 16) {
+                const uint32_t w = rec[t];
+                if (w == HJD_REC_PAD) continue;
+                const uint32_t zz = (w >> 16) & 63u;
+                const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
+                if (nat != 0) {
+                    const uint32_t pos = s_pos[zz];
+                    s_coef[blk][pos] = nat;
+                    mk |= 1ull << pos;
+                }
             }
+            if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), mk);
         }
     }
     __syncthreads();
@@ -227,10 +225,12 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
                 c2[j] = bmp ? rr[j] : bb[j];
             }
             if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
-                uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
-                d4[0] = c0[0] | (gg[0] << 8) | (c2[0] << 16) | (c0[1] << 24);
-                d4[1] = gg[1] | (c2[1] << 8) | (c0[2] << 16) | (gg[2] << 24);
-                d4[2] = c2[2] | (c0[3] << 8) | (gg[3] << 16) | (c2[3] << 24);
+                struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
+                Px12 v12;
+                v12.a = c0[0] | (gg[0] << 8) | (c2[0] << 16) | (c0[1] << 24);
+                v12.b = gg[1] | (c2[1] << 8) | (c0[2] << 16) | (gg[2] << 24);
+                v12.c = c2[2] | (c0[3] << 8) | (gg[3] << 16) | (c2[3] << 24);
+                *reinterpret_cast<Px12 *>(dst) = v12; // one 12-byte store: a wave writes 768 contiguous bytes
             } else {
                 for (uint32_t j = 0; j < nvalid; j++) {
                     dst[j * 3 + 0] = (uint8_t)c0[j];
