@@ -78,10 +78,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
+    # rehearsal knobs (not used by the driver): several ranks on one GPU need gloo and a fixed device
+    backend = os.environ.get("HJD_BENCH_BACKEND", "nccl")
+    if "HJD_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["HJD_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import hjdtools as T
     hjd = importlib.import_module("hls-jpeg-decoder_amd")
@@ -154,7 +161,7 @@ def main():
         raise SystemExit("bench: output differs from the oracle: " + parity)
 
     shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
-    dt, total_pixels = shard.agree(dt, pixels, device="cuda")  # MAX of time, SUM of pixels over the ranks
+    dt, total_pixels = shard.agree(dt, pixels, device="cuda" if backend == "nccl" else "cpu")  # MAX of time, SUM of pixels
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

@@ -14,11 +14,12 @@
 //
 // Stream layout (written by k_unstuff_write): TRANSPOSED in groups of 64 subsequences — word k of
 // subsequence i lives at word ((i/64)*(wps+2) + k)*64 + i%64, and every row is extended by the
-// first two words of the next row.  A lane's next word is a constant 256 bytes away, and the 64
-// lanes of a wave (which advance roughly in step) touch a handful of cache lines per load.
-// LDS holds only the Huffman tables (primary 10-bit tables + secondary tables for longer codes),
-// so eight workgroups fit a CU.  Waves are independent after the table load: each wave owns 64 - K
-// subsequences plus K warm-up subsequences before them and iterates with __shfl_up / __ballot.
+// first two words of the next row — so that a wave stages its 64 rows with fully coalesced loads and
+// then reads them from LDS without bank conflicts ([k*64 + lane]).
+// LDS per workgroup: the Huffman tables (primary 10-bit tables + secondary tables for longer codes,
+// shared by its 4 waves) and each wave's rows.  Waves are independent after the table load: each wave
+// owns 64 - K subsequences plus K warm-up subsequences before them and iterates with __shfl_up /
+// __ballot.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -60,43 +61,10 @@ __device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp
 // window() = the next 32 bits; advance(n) consumes n <= 31 bits.  State: words hi, lo and sh = number
 // of unconsumed bits of hi (0..31); window = alignbit(hi, lo, sh).
 
-// k_sync: straight from the transposed stream in global memory (L1/L2-resident, lanes of a wave read
-// neighbouring addresses).  Two words are kept in flight so that a load is consumed two reloads
-// after it was issued; the loop issues no other vector-memory operation, so the wait is for old loads.
-struct ReaderGlobal {
-    uint32_t hi, lo, n1, n2, sh;
-    const uint32_t *gp;
-    __device__ __forceinline__ void init(const uint32_t *rowp, uint32_t rel)
-    {
-        const uint32_t k0 = rel >> 5, o0 = rel & 31u;
-        const uint32_t *sp = rowp + k0 * 64u;
-        const uint32_t a = sp[0], b = sp[64], c = sp[128], d = sp[192];
-        hi = a;
-        lo = o0 ? b : a;
-        n1 = o0 ? c : b;
-        n2 = o0 ? d : c;
-        gp = sp + (o0 ? 256 : 192);
-        sh = (32u - o0) & 31u;
-    }
-    __device__ __forceinline__ void prefetch() {}
-    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-    __device__ __forceinline__ void advance(uint32_t tot)
-    {
-        const int sh2 = (int)sh - (int)tot;
-        if (sh2 < 0) {
-            hi = lo;
-            lo = n1;
-            n1 = n2;
-            n2 = *gp;
-            gp += 64;
-        }
-        sh = (uint32_t)sh2 & 31u;
-    }
-};
-
-// k_write: the wave's 64 rows are staged in LDS first ([k*64 + lane], coalesced 16-byte loads), so
-// that the loop's only vector-memory operations are the coefficient stores, which it never waits for
-// (loads and stores share one counter on gfx9-class hardware).
+// Both kernels stage the wave's 64 rows in LDS first ([k*64 + lane], coalesced loads), so that the
+// loop's only vector-memory operations are k_write's record stores, which it never waits for (loads
+// and stores share one counter on gfx9-class hardware; reading the stream from L1 inside the loop
+// was measured 2x slower for k_write and no faster for k_sync).
 struct ReaderLds {
     uint32_t hi, lo, nxt, sh;
     const uint32_t *nx;
