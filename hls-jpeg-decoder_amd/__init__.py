@@ -141,12 +141,15 @@ class Decoder:
             raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             lib().hjd_decoder_destroy(self._h)
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def prepare(self, jpgs, out_format=OUT_RGB):
         return Batch(self, jpgs, out_format)
@@ -179,12 +182,15 @@ class Batch:
         self.parse_status = list(st)
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             lib().hjd_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
     def run(self, stream=None):
         rc = lib().hjd_batch_run(self._h, stream)

@@ -29,7 +29,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct hjd_decoder {
     int device = 0;
     uint32_t subseq_bits = 1024;
-    int sync_launches = 2; // one synchronisation launch + one (normally empty) repair launch
+    int sync_launches = 3; // one synchronisation launch + two repair launches (the second is empty unless a
+                           // repaired chain ran across the border of the first one's waves)
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
 };
 

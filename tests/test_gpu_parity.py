@@ -159,6 +159,43 @@ def test_mixed_restart_batch(hjd, dec):
             assert s == hjd.HJD_ERR_DIRTY_RESTART
 
 
+def test_extreme_aspect_ratios(hjd, dec):
+    """Ragged shapes: one MCU row / one MCU column, widths and heights far from MCU multiples."""
+    for (w, h, hf, vf) in [(4099, 9, 2, 2), (7, 3001, 2, 2), (2500, 1, 1, 1), (1, 777, 2, 1), (8192, 16, 2, 2)]:
+        data = T.synth_jpeg(w, h, w + h, 85, hf, vf)
+        st, outs = dec.decode([data], hjd.OUT_BMP)
+        assert st == [0], (w, h, st)
+        orc, orgb, _, _, _ = T.oracle_decode(data)
+        assert orc == 0 and outs[0].tobytes() == T.oracle_bmp(orgb), (w, h)
+
+
+def test_bit_flipped_scans_never_crash_and_never_lie(hjd, dec):
+    """Corrupt entropy data: the GPU path must terminate, and whenever it reports success its bytes
+    must be the oracle's (which restates what the reference computes on that exact stream); whenever the
+    oracle says the reference would hang / overrun / lose a DC code, the GPU must report an error."""
+    rng = np.random.default_rng(2024)
+    base = [T.synth_jpeg(160, 120, 5, 85, 2, 2), T.synth_jpeg(120, 88, 6, 60, 1, 1), T.synth_jpeg(200, 64, 7, 90, 2, 1, 4, 7.0)]
+    jpgs = []
+    for k in range(45):
+        b = bytearray(base[k % 3])
+        sos = b.index(b"\xff\xda")
+        for _ in range(1 + k % 3):
+            pos = int(rng.integers(sos + 14, len(b) - 2))
+            b[pos] ^= 1 << int(rng.integers(0, 8))
+        jpgs.append(bytes(b))
+    st, outs = dec.decode(jpgs)
+    agree = 0
+    for j, s, o in zip(jpgs, st, outs):
+        orc, orgb, _, _, ost = T.oracle_decode(j)
+        if s == 0:
+            assert orc == 0, "GPU decoded a stream the reference cannot"
+            assert np.array_equal(o, orgb)
+            agree += 1
+        if orc in (T.HJO_ERR_REF_WOULD_HANG, T.HJO_ERR_REF_OVERRUN, T.HJO_ERR_DC_CODE_MISSING):
+            assert s != 0
+    assert agree >= 5  # a good share of single-bit flips stay decodable (and must then match exactly)
+
+
 def test_statuses(hjd, dec, golden):
     d, man = golden
     bad = [open(os.path.join(d, n), "rb").read() for n in ("pil_progressive.jpg", "pil_gray.jpg")]
