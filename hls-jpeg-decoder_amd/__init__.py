@@ -54,7 +54,13 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError("libhjd.so not built (%s): run `make lib`; there is no CPU fallback" % LIB_PATH)
+        # build on demand (hipcc cross-compiles for gfx950 without a GPU); never a substitute implementation
+        import subprocess
+        root = os.path.dirname(_HERE)
+        r = subprocess.run(["make", "-s", "lib"], cwd=root, capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(LIB_PATH):
+            raise RuntimeError("libhjd.so not built (%s) and `make lib` failed: %s\nthere is no CPU fallback"
+                               % (LIB_PATH, r.stderr[-2000:]))
     L = ctypes.CDLL(LIB_PATH)
     vp, ip, sz = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t
     L.hjd_status_string.restype = ctypes.c_char_p

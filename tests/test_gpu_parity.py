@@ -196,6 +196,31 @@ def test_bit_flipped_scans_never_crash_and_never_lie(hjd, dec):
     assert agree >= 5  # a good share of single-bit flips stay decodable (and must then match exactly)
 
 
+def test_config3_batch_of_1080p(hjd, dec):
+    """BASELINE config 3 shape (a large batch of 1920x1080 4:2:0 q85), scaled to 192 images: every image
+    equals the oracle's output for its source, replicas of one source are byte-identical (determinism), and
+    a second run of the same batch reproduces the first (idempotence)."""
+    src = [T.synth_jpeg(1920, 1080, 500 + k, 85, 2, 2) for k in range(6)]
+    ref = [T.oracle_decode(j)[1] for j in src]
+    jpgs = [src[i % 6] for i in range(192)]
+    b = dec.prepare(jpgs)
+    b.run()
+    assert b.finish() == [0] * 192
+    import zlib
+    first = []
+    for i in range(192):
+        o = b.download(i)
+        if i < 6:
+            assert np.array_equal(o, ref[i])
+        first.append(zlib.crc32(o.tobytes()))
+    assert all(first[i] == first[i % 6] for i in range(192))
+    b.run()
+    assert b.finish() == [0] * 192
+    assert [zlib.crc32(b.download(i).tobytes()) for i in range(0, 192, 17)] == first[0:192:17]
+    assert b.resync_count() == 0
+    b.close()
+
+
 def test_statuses(hjd, dec, golden):
     d, man = golden
     bad = [open(os.path.join(d, n), "rb").read() for n in ("pil_progressive.jpg", "pil_gray.jpg")]
