@@ -34,7 +34,8 @@
 //   code length 0: the code is longer than HJD_LUT_BITS; bits 5-15 = 1 + index of the secondary
 //   table for this prefix (0 = no code has this prefix).  Secondary tables are indexed by the next
 //   HJD_SEC_BITS bits and hold entries of the same format (length 0 = no such code).
-#define HJD_SEC_BITS 6
+#define HJD_SEC_BITS (16 - HJD_LUT_BITS)
+#define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
 #define HJD_MAX_SEC 64
 struct HjdTableSet {
     uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)

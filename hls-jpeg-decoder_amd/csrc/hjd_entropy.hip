@@ -29,7 +29,7 @@
 
 struct EntropyLds {
     const uint16_t *lut; // [nlut][1024]
-    const uint16_t *sec; // [nsec][64]
+    const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
 };
 
 // address of word 0 of subsequence (row) i in the transposed stream; successive words are 64 words apart
@@ -40,7 +40,7 @@ __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t 
 
 __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
 {
-    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * 2 / 16), ns = ts->nsec * (64 * 2 / 16);
+    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * 2 / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(&ts->lut[0][0]);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
     for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) dst[k] = src[k];
@@ -145,10 +145,10 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         const uint32_t win = rd.window();
         uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
         if ((e & 31u) == 0u) {
-            // code longer than HJD_LUT_BITS: second-level table on the next 6 bits (IsInHuffmanCodes,
+            // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
             // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
             const uint32_t sub = e >> 5;
-            e = sub ? L.sec[(sub - 1u) * 64u + ((win >> 16) & 63u)] : 0u;
+            e = sub ? L.sec[(sub - 1u) * HJD_SEC_SIZE + ((win >> 16) & (HJD_SEC_SIZE - 1u))] : 0u;
             if ((e & 31u) == 0u) {
                 if (WRITE) flags |= HJD_FLAG_BAD_CODE;
                 e = 16u; // skip 16 bits: any progress will do, the result is discarded or flagged

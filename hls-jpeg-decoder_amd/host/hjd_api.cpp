@@ -415,7 +415,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     {   // dynamic LDS of the entropy kernels: transposed stream rows, then primary and secondary tables
         P.lds_lut_word = 0;
         P.lds_sec_word = P.lds_lut_word + max_nlut * HJD_LUT_SIZE / 2;
-        P.lds_stream_word = (P.lds_sec_word + max_nsec * 32 + 3) & ~3u;
+        P.lds_stream_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_bytes = (P.lds_stream_word + (HJD_SYNC_WG / 64) * ((S / 32) + 2) * 64) * 4;
     }
     return HJD_OK;

@@ -221,6 +221,35 @@ def test_config3_batch_of_1080p(hjd, dec):
     b.close()
 
 
+def test_reference_shaped_entry_points(hjd, golden):
+    """The three single-image entry points that mirror the reference's API surface:
+    hjd_jpeg_decode_hw (JpegDecodeHW, loadjpg.h:180 — parsed tables in, RGB out, argument order height, width),
+    hjd_decode_jpg_file_data (DecodeJpgFileData, openjpg.h:25-27) and hjd_convert_jpg_file (ConvertJpgFile)."""
+    import ctypes
+    d, man = golden
+    L = hjd.lib()
+    for name in ("Lenna.jpg", "syn_250x187_422_q85.jpg", "pil_250x187_420_q85_opt.jpg", "syn_256x192_420_q85_rst16.jpg"):
+        data = open(os.path.join(d, name), "rb").read()
+        orc, orgb, _, _, _ = T.oracle_decode(data)
+        st, jd = hjd.parse_header(data)
+        assert st == 0
+        out = np.zeros((jd.height, jd.width, 3), np.uint8)
+        rc = L.hjd_jpeg_decode_hw(ctypes.byref(jd), jd.height, jd.width, jd.hfactor, jd.vfactor, out.ctypes.data)
+        assert rc == 0, (name, rc)
+        assert np.array_equal(out, orgb), name
+        # memory in, callee-allocated RGB out
+        rgb, w, h = ctypes.c_void_p(), ctypes.c_uint(), ctypes.c_uint()
+        assert L.hjd_decode_jpg_file_data(data, len(data), ctypes.byref(rgb), ctypes.byref(w), ctypes.byref(h)) == 1
+        got = np.ctypeslib.as_array(ctypes.cast(rgb, ctypes.POINTER(ctypes.c_uint8)), shape=(h.value, w.value, 3)).copy()
+        L.hjd_free(rgb)
+        assert np.array_equal(got, orgb), name
+    # hFactor = 0 is a SIGFPE in the reference (loadjpg.cpp:1153); here it is a status
+    assert L.hjd_jpeg_decode_hw(ctypes.byref(jd), jd.height, jd.width, 0, 1, out.ctypes.data) == hjd.HJD_ERR_UNSUPPORTED
+    rgb, w, h = ctypes.c_void_p(), ctypes.c_uint(), ctypes.c_uint()
+    assert L.hjd_decode_jpg_file_data(b"garbage!", 8, ctypes.byref(rgb), ctypes.byref(w), ctypes.byref(h)) == 0
+    assert L.hjd_last_status() == hjd.HJD_ERR_NOT_JPEG
+
+
 def test_statuses(hjd, dec, golden):
     d, man = golden
     bad = [open(os.path.join(d, n), "rb").read() for n in ("pil_progressive.jpg", "pil_gray.jpg")]
