@@ -209,10 +209,32 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             const uint8_t *pcb = &s_pix[k * nb + nby][cy * 8];
             const uint8_t *pcr = &s_pix[k * nb + nby + 1][cy * 8];
             uint32_t rr[4], gg[4], bb[4];
+            if (hf == 2) {
+                // 4:2:x — pixels 0,1 and 2,3 share a chroma sample (cx = x/2, loadjpg.cpp:912): the four
+                // chroma products are formed once per sample; every operation is the same fp32 operation
+                // ConvertYCrCbtoRGB performs ((float)(c - 128) == (float)c - 128.0f exactly)
+                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb[xin >> 1]);
+                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr[xin >> 1]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t cx = (xin + j) / hf; // loadjpg.cpp:912
-                ycc_to_rgb((int)((ypix >> (8 * j)) & 0xFF), (int)pcb[cx], (int)pcr[cx], rr[j], gg[j], bb[j]);
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const float fcb = (float)((cb2 >> (8 * h2)) & 0xFF) - 128.0f;
+                    const float fcr = (float)((cr2 >> (8 * h2)) & 0xFF) - 128.0f;
+                    const float pa = 1.402f * fcr, pb = 0.34414f * fcb, pc = 0.71414f * fcr, pd = 1.772f * fcb;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int j = 2 * h2 + q;
+                        const float fy = (float)((ypix >> (8 * j)) & 0xFF);
+                        rr[j] = clamp255((int)(fy + pa));
+                        gg[j] = clamp255((int)((fy - pb) - pc));
+                        bb[j] = clamp255((int)(fy + pd));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t cx = (xin + j) / hf; // loadjpg.cpp:912
+                    ycc_to_rgb((int)((ypix >> (8 * j)) & 0xFF), (int)pcb[cx], (int)pcr[cx], rr[j], gg[j], bb[j]);
+                }
             }
             const uint32_t nvalid = min(4u, W - gxp);
             uint8_t *dst;
