@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ uint8_t s_order[MAXGB];
     __shared__ uint32_t s_hist[66];
     __shared__ uint32_t s_boff[MAXGB + 1];
+    __shared__ uint8_t s_comp[MAXGB];     // component (0 Y, 1 Cb, 2 Cr) of every block of the group
 
     const uint32_t tid = threadIdx.x;
     const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         s_cos[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
     }
     if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
+    if (tid < KB) {
+        const uint32_t mm = tid % nb;
+        s_comp[tid] = (uint8_t)(mm < nby ? 0u : mm - nby + 1u);
+    }
     if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
     if (tid < 64) { // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
         const uint32_t u = tid >> 3, v = tid & 7;
@@ -94,8 +99,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         const uint32_t *boff = P.boff + im.boff_off + b0;
         if (tid <= KB) s_boff[tid] = min(boff[tid], im.rec_cap);
         if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0
-            const uint32_t mm = tid % nb;
-            const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
+            const uint32_t comp = s_comp[tid];
             const int16_t nat = (int16_t)((int)P.dca[im.blk_off + b0 + tid] * (int)s_qt[comp][0]);
             s_coef[tid][0] = nat;
             s_mask[tid] = nat != 0 ? 1ull : 0ull;
@@ -105,8 +109,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         // loads coalesce); r1 < r0 after a corrupt stream simply yields no work
         for (uint32_t blk = tid >> 4; blk < KB; blk += 16) {
             const uint32_t r0 = s_boff[blk], r1 = s_boff[blk + 1];
-            const uint32_t mm = blk % nb;
-            const uint32_t comp = mm < nby ? 0u : mm - nby + 1u;
+            const uint32_t comp = s_comp[blk];
             unsigned long long mk = 0;
             for (uint32_t t = r0 + (tid & 15u); t < r1; t += 16) {
                 const uint32_t w = rec[t];
@@ -191,21 +194,26 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     {
         const uint32_t W = im.width, H = im.height;
         const uint32_t mw = 8 * hf, mh = 8 * vf;
-        const uint32_t upr = K * 2 * hf; // 4-pixel units per row
-        const uint32_t nunits = upr * mh;
+        // hf, vf are 1, 2 or 4 (hjd_parse_header): all index arithmetic below is shifts and masks.  The
+        // unit grid is padded to HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields.
+        const uint32_t lhf = hf >> 1, lvf = vf >> 1; // log2 for 1, 2, 4
+        const uint32_t upr = K * 2 * hf;             // valid 4-pixel units per row
+        const uint32_t lupr = 5 + lhf;               // log2(HJD_GROUP_MCUS * 2 * hf)
+        const uint32_t nunits = mh << lupr;
         uint8_t *out = P.out + im.out_off;
         const bool bmp = im.out_format == 1;
         const uint32_t stride = im.out_stride;
         for (uint32_t t = tid; t < nunits; t += 256) {
-            const uint32_t row = t / upr, ux = t % upr;
+            const uint32_t row = t >> lupr, ux = t & ((1u << lupr) - 1u);
+            if (ux >= upr) continue;
             const uint32_t px = ux * 4;
-            const uint32_t k = px / mw, xin = px % mw;
+            const uint32_t k = px >> (3 + lhf), xin = px & (mw - 1u);
             const uint32_t gy = mrow * mh + row;
             const uint32_t gxp = (mcu_first + k) * mw + xin;
             if (gy >= H || gxp >= W) continue; // loadjpg.cpp:907-908
-            const uint32_t yblk = k * nb + (row >> 3) * hf + (xin >> 3);
+            const uint32_t yblk = k * nb + ((row >> 3) << lhf) + (xin >> 3);
             const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[yblk][(row & 7) * 8 + (xin & 7)]);
-            const uint32_t cy = row / vf;
+            const uint32_t cy = row >> lvf;
             const uint8_t *pcb = &s_pix[k * nb + nby][cy * 8];
             const uint8_t *pcr = &s_pix[k * nb + nby + 1][cy * 8];
             uint32_t rr[4], gg[4], bb[4];
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t cx = (xin + j) / hf; // loadjpg.cpp:912
+                    const uint32_t cx = (xin + j) >> lhf; // loadjpg.cpp:912
                     ycc_to_rgb((int)((ypix >> (8 * j)) & 0xFF), (int)pcb[cx], (int)pcr[cx], rr[j], gg[j], bb[j]);
                 }
             }
