@@ -168,7 +168,7 @@ def main():
         value = total_pixels * args.steps / dt / 1e6
         stage_ms = {n: round(ms, 4) for n, ms in stages}
         dom = max(stages, key=lambda x: x[1]) if stages else ("none", 0.0)
-        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "scan": "k_scan",
+        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair (x2)", "scan": "k_scan",
                      "huff_write": "k_write", "idct_color": "k_idct_color", "mask_clear": "hipMemsetAsync",
                      "reset": "hipMemsetAsync"}
         achieved = launch_alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0

@@ -483,6 +483,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         if (hjd_launch_unstuff(P, b->nchunks, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_sync"))) return rc;
         if (hjd_launch_sync(P, b->nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        if ((rc = mark("huff_repair"))) return rc;
         for (int l = 1; l < b->dec->sync_launches; l++)
             if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
     } else {

@@ -15,7 +15,7 @@ import glob
 import json
 import sys
 
-STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_write": "huff_write",
+STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair", "k_write": "huff_write",
             "k_unstuff_write": "unstuff", "k_dcapply": "dc_scan", "k_scan": "scan"}
 
 
