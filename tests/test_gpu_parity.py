@@ -221,6 +221,15 @@ def test_config3_batch_of_1080p(hjd, dec):
     b.close()
 
 
+def test_large_image(hjd, dec):
+    """64 Mpixel image (8192x8192, 4:2:0): 1.5 M blocks, ~90 k subsequences, ~16 M records in one image."""
+    data = T.synth_jpeg(8192, 8192, 4242, 85, 2, 2)
+    st, outs = dec.decode([data])
+    assert st == [0]
+    orc, orgb, _, _, _ = T.oracle_decode(data)
+    assert orc == 0 and np.array_equal(outs[0], orgb)
+
+
 def test_reference_shaped_entry_points(hjd, golden):
     """The three single-image entry points that mirror the reference's API surface:
     hjd_jpeg_decode_hw (JpegDecodeHW, loadjpg.h:180 — parsed tables in, RGB out, argument order height, width),
