@@ -88,3 +88,15 @@ def test_product_does_not_reference_oracle():
                 if "hjd_oracle" in txt or "oracle/" in txt or "hjo_" in txt:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/main.cpp"), reason="reference sources only exist in the build container")
+def test_reference_main_links_against_the_library(hjd, tmp_path):
+    """the reference's own main.cpp (which calls ConvertJpgFile, main.cpp:33) links against
+    libhjd.so with openjpg.cpp / loadjpg.cpp dropped from the link."""
+    import subprocess
+    exe = str(tmp_path / "refmain")
+    r = subprocess.run(["hipcc", "-O2", "-w", "-I/root/reference/src", "/root/reference/src/main.cpp",
+                        "-L" + os.path.dirname(hjd.LIB_PATH), "-lhjd", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(exe)
