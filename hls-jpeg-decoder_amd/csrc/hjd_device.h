@@ -2,10 +2,11 @@
 //
 // Everything a kernel reads lives in HBM slabs owned by a batch:
 //   raw      : the stuffed scan bytes of all images, image i at raw_off (16-B aligned, padded)
-//   ustream  : the unstuffed scans as MSB-first 32-bit words (byte k of the bit string is
-//              stored at address k^3), image i at ustream_off
+//   ustream  : the unstuffed scans as MSB-first 32-bit words, transposed in groups of 64 subsequences
+//              (word k of subsequence i at ((i/64)*(wps+2) + k)*64 + i%64, rows extended by two words),
+//              image i at ustream_off
 //   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
-//   substart : exclusive prefix sums over sub (first block index, DC predictors)
+//   substart : exclusive prefix sums over sub (first block index, first record index)
 //   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16; all ones =
 //              padding), every subsequence's run rounded up to HJD_REC_RUN records so that it is
 //              written in aligned bursts; boff[b] = index of block b's first record (boff[nblocks] = end)
