@@ -259,6 +259,14 @@ def test_reference_shaped_entry_points(hjd, golden):
     assert L.hjd_last_status() == hjd.HJD_ERR_NOT_JPEG
 
 
+def test_empty_and_all_bad_batches(hjd, dec):
+    """Ragged inputs at the batch level: no images, and only images that fail to parse."""
+    st, outs = dec.decode([])
+    assert st == [] and outs == []
+    st, outs = dec.decode([b"", b"\xff\xd8", b"not a jpeg"])
+    assert all(s != 0 for s in st) and outs == [None, None, None]
+
+
 def test_statuses(hjd, dec, golden):
     d, man = golden
     bad = [open(os.path.join(d, n), "rb").read() for n in ("pil_progressive.jpg", "pil_gray.jpg")]
