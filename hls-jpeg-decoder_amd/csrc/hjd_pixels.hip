@@ -106,21 +106,40 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         }
         __syncthreads();
         // sixteen threads per block walk its record range [boff[b], boff[b+1]) (contiguous, so the team's
-        // loads coalesce); r1 < r0 after a corrupt stream simply yields no work
-        for (uint32_t blk = tid >> 4; blk < KB; blk += 16) {
-            const uint32_t r0 = s_boff[blk], r1 = s_boff[blk + 1];
+        // loads coalesce); r1 < r0 after a corrupt stream simply yields no work.  The first record of
+        // every (thread, block) pair is requested before any is used, so that a workgroup pays the global
+        // memory latency once instead of once per pass.
+        constexpr int NPASS = MAXGB / 16;
+        uint32_t w0[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; k++) {
+            const uint32_t blk = (tid >> 4) + 16u * k;
+            w0[k] = HJD_REC_PAD;
+            if (blk < KB) {
+                const uint32_t t = s_boff[blk] + (tid & 15u);
+                if (t < s_boff[blk + 1]) w0[k] = rec[t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPASS; k++) {
+            const uint32_t blk = (tid >> 4) + 16u * k;
+            if (blk >= KB) break;
+            const uint32_t r1 = s_boff[blk + 1];
             const uint32_t comp = s_comp[blk];
             unsigned long long mk = 0;
-            for (uint32_t t = r0 + (tid & 15u); t < r1; t += 16) {
-                const uint32_t w = rec[t];
-                if (w == HJD_REC_PAD) continue;
-                const uint32_t zz = (w >> 16) & 63u;
-                const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
-                if (nat != 0) {
-                    const uint32_t pos = s_pos[zz];
-                    s_coef[blk][pos] = nat;
-                    mk |= 1ull << pos;
+            uint32_t w = w0[k];
+            for (uint32_t t = s_boff[blk] + (tid & 15u); t < r1;) {
+                if (w != HJD_REC_PAD) {
+                    const uint32_t zz = (w >> 16) & 63u;
+                    const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
+                    if (nat != 0) {
+                        const uint32_t pos = s_pos[zz];
+                        s_coef[blk][pos] = nat;
+                        mk |= 1ull << pos;
+                    }
                 }
+                t += 16;
+                if (t < r1) w = rec[t]; // blocks with more than 16 records (rare)
             }
             if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), mk);
         }
