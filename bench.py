@@ -31,6 +31,14 @@ def cpu_baseline(jpgs, w, h):
     sources, single-threaded like the reference); 'port' = our C restatement (oracle/)."""
     import hjdtools as T
     ncores = os.cpu_count()
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     exe = T.ref_binary(big=True)
     sample = jpgs[:2]
     with tempfile.TemporaryDirectory() as td:
@@ -51,8 +59,8 @@ def cpu_baseline(jpgs, w, h):
             dt = time.time() - t0
             kind = "port"
     return {"value": round(len(sample) * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": "%d x %dx%d 4:2:0 q85 JPEG -> BMP, single thread (host has %d cores), incl. file I/O"
-                      % (len(sample), w, h, ncores)}
+            "sample": "%d x %dx%d 4:2:0 q85 JPEG -> BMP, single thread on %s (host has %d cores), incl. file I/O"
+                      % (len(sample), w, h, model, ncores)}
 
 
 def main():
