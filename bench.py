@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images replicated to fill the batch")
     ap.add_argument("--subseq-bits", type=int, default=0)
     ap.add_argument("--streams", type=int, default=4, help="split the per-GPU batch over this many HIP streams")
+    ap.add_argument("--internal-streams", type=int, default=0,
+                    help="instead: ONE batch, split inside the library (hjd_options.streams); no per-stage timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,7 +112,9 @@ def main():
     distinct = [T.synth_jpeg(W, H, 1000 + 17 * rank + k, args.quality, 2, 2) for k in range(max(1, args.distinct))]
     jpgs = [distinct[i % len(distinct)] for i in range(args.batch)]
 
-    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits)
+    if args.internal_streams > 1:
+        args.streams = 1
+    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=args.internal_streams)
     # parse + H2D: inputs are resident in HBM from here on.  The per-GPU batch may be split into
     # sub-batches that run on separate HIP streams, so that one sub-batch's latency-bound
     # synchronisation tail overlaps another's IDCT (same total work per step).
@@ -140,8 +144,9 @@ def main():
         st = b.finish(sh)
         assert all(s == 0 for s in st), st
 
-    for b in batches:
-        b.enable_timing(args.steps)
+    if args.internal_streams <= 1:
+        for b in batches:
+            b.enable_timing(args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -159,7 +164,8 @@ def main():
         stg, runs = b.collect_timing()
         stages_all.append(stg)
     # per-launch stage durations: average over the sub-batches' launches (each launch covers 1/ns of the batch)
-    stages = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))]
+    stages = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))] \
+        if stages_all and stages_all[0] else []
     launch_alg_bytes = alg_bytes / ns
 
     # parity of what was just timed: compare images of the batch with the CPU oracle (checker only)

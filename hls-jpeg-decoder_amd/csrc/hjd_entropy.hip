@@ -255,10 +255,11 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
 
     const uint32_t lane = threadIdx.x & 63u;
-    const int ii = mode == 0 ? find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.syncwg0; })
-                             : find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
+    const uint32_t bid = blockIdx.x + (mode == 0 ? P.off_syncwg : P.off_writewg);
+    const int ii = mode == 0 ? find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.syncwg0; })
+                             : find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
     const HjdImage &im = P.img[ii];
-    const uint32_t wv = (blockIdx.x - (mode == 0 ? im.syncwg0 : im.writewg0)) * (HJD_SYNC_WG / 64) + (threadIdx.x >> 6);
+    const uint32_t wv = (bid - (mode == 0 ? im.syncwg0 : im.writewg0)) * (HJD_SYNC_WG / 64) + (threadIdx.x >> 6);
     const uint32_t K = mode == 0 ? P.sync_overlap : 0u, Q = 64u - K;
     const uint32_t own0 = wv * Q, own1 = own0 + Q;
     const uint32_t row0 = own0 >= K ? own0 - K : 0u;
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
 
-    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.writewg0; });
+    const uint32_t bid = blockIdx.x + P.off_writewg;
+    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
     const HjdImage &im = P.img[ii];
 
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = (blockIdx.x - im.writewg0) * HJD_SYNC_WG + threadIdx.x;
+    const uint32_t i = (bid - im.writewg0) * HJD_SYNC_WG + threadIdx.x;
     // stage this wave's group of 64 rows: (wps+2) x 256 contiguous bytes of the transposed stream
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t rowwords = ((1u << P.log2_words) + 2u) * 64u;

@@ -25,6 +25,9 @@ struct HjdParams {
     uint32_t ndcchunks;
     uint8_t *out;              // RGB / BMP bytes
     int nimg;
+    // A launch may cover only a contiguous range of images (sub-batches on separate streams): these are
+    // added to blockIdx.x so that every kernel still sees batch-global workgroup / image numbers.
+    uint32_t off_chunk, off_syncwg, off_writewg, off_img, off_dcchunk, off_group;
     uint32_t subseq_bits;      // power of two, 64..2048
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences shared with the previous synchronisation workgroup
@@ -36,7 +39,7 @@ struct HjdParams {
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int launch_idx, hipStream_t s);
-int hjd_launch_scan(const HjdParams &P, hipStream_t s);
-int hjd_launch_dcscan(const HjdParams &P, hipStream_t s);
+int hjd_launch_scan(const HjdParams &P, uint32_t nimg, hipStream_t s);
+int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

@@ -65,9 +65,10 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ uint8_t s_comp[MAXGB];     // component (0 Y, 1 Cb, 2 Cr) of every block of the group
 
     const uint32_t tid = threadIdx.x;
-    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &m) { return m.group0; });
+    const uint32_t bid = blockIdx.x + P.off_group;
+    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &m) { return m.group0; });
     const HjdImage &im = P.img[ii];
-    const uint32_t lg = blockIdx.x - im.group0;
+    const uint32_t lg = bid - im.group0;
     const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;
     const uint32_t mcu_first = gx * HJD_GROUP_MCUS;
     const uint32_t K = min((uint32_t)HJD_GROUP_MCUS, im.mcux - mcu_first);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
 {
     __shared__ uint8_t s_edge[512];
     __shared__ uint32_t s_w[17];
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
     const HjdImage &im = P.img[ii];
     uint4 v;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     __shared__ uint8_t s_edge[512];
     __shared__ __attribute__((aligned(4))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 8];
     __shared__ uint32_t s_w[17];
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
     const HjdImage &im = P.img[ii];
     const uint32_t lc = c - im.chunk0;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 __global__ __launch_bounds__(1024) void k_scan(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
-    const int ii = blockIdx.x;
+    const int ii = (int)(blockIdx.x + P.off_img);
     const HjdImage &im = P.img[ii];
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
@@ -225,10 +225,11 @@ __device__ __forceinline__ void dc_thread_sums(const int16_t *d, uint32_t m0, ui
 __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
-    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.dcchunk0; });
+    const uint32_t bid = blockIdx.x + P.off_dcchunk;
+    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.dcchunk0; });
     const HjdImage &im = P.img[ii];
     const uint32_t nmcu = im.mcux * im.mcuy;
-    const uint32_t c0 = (blockIdx.x - im.dcchunk0) * HJD_DC_CHUNK;
+    const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     uint32_t y, cb, cr, ty, tcb, tcr;
     dc_thread_sums(P.dcd + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
@@ -236,20 +237,21 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
     block_excl_scan(cb, s_w, &tcb);
     block_excl_scan(cr, s_w, &tcr);
     if (threadIdx.x == 0) {
-        P.dcsum[blockIdx.x * 3 + 0] = ty;
-        P.dcsum[blockIdx.x * 3 + 1] = tcb;
-        P.dcsum[blockIdx.x * 3 + 2] = tcr;
+        P.dcsum[bid * 3 + 0] = ty;
+        P.dcsum[bid * 3 + 1] = tcb;
+        P.dcsum[bid * 3 + 2] = tcr;
     }
 }
 
 __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
-    const int ii = find_image(P.img, P.nimg, blockIdx.x, [](const HjdImage &q) { return q.dcchunk0; });
+    const uint32_t bid = blockIdx.x + P.off_dcchunk;
+    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.dcchunk0; });
     const HjdImage &im = P.img[ii];
     const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t nmcu = im.mcux * im.mcuy;
-    const uint32_t lc = blockIdx.x - im.dcchunk0;
+    const uint32_t lc = bid - im.dcchunk0;
     // totals of this image's earlier chunks
     uint32_t py = 0, pcb = 0, pcr = 0, t;
     for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
@@ -299,21 +301,20 @@ int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s)
     return 0;
 }
 
-int hjd_launch_scan(const HjdParams &P, hipStream_t s)
+int hjd_launch_scan(const HjdParams &P, uint32_t nimg, hipStream_t s)
 {
-    if (!P.nimg) return 0;
-    hipLaunchKernelGGL(k_scan, dim3(P.nimg), dim3(1024), 0, s, P);
+    if (!nimg) return 0;
+    hipLaunchKernelGGL(k_scan, dim3(nimg), dim3(1024), 0, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }
 
-int hjd_launch_dcscan(const HjdParams &P, hipStream_t s)
+int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s)
 {
-    if (!P.nimg) return 0;
-    if (!P.ndcchunks) return 0;
-    hipLaunchKernelGGL(k_dcsum, dim3(P.ndcchunks), dim3(256), 0, s, P);
+    if (!nchunks) return 0;
+    hipLaunchKernelGGL(k_dcsum, dim3(nchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_dcapply, dim3(P.ndcchunks), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_dcapply, dim3(nchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }

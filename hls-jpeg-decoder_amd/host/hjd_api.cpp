@@ -32,6 +32,7 @@ struct hjd_decoder {
     int sync_launches = 3; // one synchronisation launch + two repair launches (the second is empty unless a
                            // repaired chain ran across the border of the first one's waves)
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
+    int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
 };
 
 struct hjd_batch {
@@ -45,6 +46,13 @@ struct hjd_batch {
     std::vector<size_t> hdr_bytes;
     std::vector<HjdImageState> state;
     int out_format = 0;
+    // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
+    // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
+    struct Range { int i0, i1; uint32_t chunk0, nchunk, syncwg0, nsyncwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t boff0, nboff; };
+    std::vector<Range> ranges;
+    std::vector<hipStream_t> istreams;
+    std::vector<hipEvent_t> join_ev;
+    hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
@@ -187,6 +195,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
             d->subseq_bits = (uint32_t)opt->subseq_bits;
         }
         if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
+        if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 2048 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
@@ -226,6 +235,9 @@ static void batch_free_device(hjd_batch *b)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
         for (auto &e : v) (void)hipEventDestroy(e);
+    for (auto &st : b->istreams) (void)hipStreamDestroy(st);
+    for (auto &e : b->join_ev) (void)hipEventDestroy(e);
+    if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
 }
 
 extern "C" void hjd_batch_destroy(hjd_batch *b)
@@ -408,6 +420,45 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
+    P.off_chunk = P.off_syncwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
+    {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
+        int ns = d->streams;
+        if (ns > b->nimg) ns = b->nimg;
+        if (ns < 1) ns = 1;
+        uint64_t total_px = 0;
+        for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
+        int i0 = 0;
+        uint64_t acc = 0;
+        for (int k = 0; k < ns; k++) {
+            int i1 = i0;
+            const uint64_t target = total_px * (uint64_t)(k + 1) / (uint64_t)ns;
+            while (i1 < b->nimg && (acc < target || i1 == i0) && (b->nimg - i1) > (ns - 1 - k)) {
+                acc += (uint64_t)b->img[i1].width * b->img[i1].height;
+                i1++;
+            }
+            if (k == ns - 1) i1 = b->nimg;
+            hjd_batch::Range r{};
+            r.i0 = i0;
+            r.i1 = i1;
+            const HjdImage &a = b->img[i0], &z = b->img[i1 - 1];
+            r.chunk0 = a.chunk0;       r.nchunk = z.chunk0 + z.nchunks - a.chunk0;
+            r.syncwg0 = a.syncwg0;     r.nsyncwg = z.syncwg0 + z.nsyncwg - a.syncwg0;
+            r.writewg0 = a.writewg0;   r.nwritewg = z.writewg0 + z.nwritewg - a.writewg0;
+            r.dc0 = a.dcchunk0;        r.ndc = z.dcchunk0 + z.ndcchunk - a.dcchunk0;
+            r.group0 = a.group0;       r.ngroup = z.group0 + z.ngroups - a.group0;
+            r.boff0 = (size_t)a.boff_off;
+            r.nboff = (size_t)(z.boff_off + z.nblocks + 1 - a.boff_off);
+            b->ranges.push_back(r);
+            i0 = i1;
+        }
+        if (b->ranges.size() > 1) {
+            b->istreams.resize(b->ranges.size());
+            b->join_ev.resize(b->ranges.size());
+            for (auto &st : b->istreams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            for (auto &e : b->join_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+        }
+    }
     P.subseq_bits = S;
     P.log2_words = 0;
     while ((32u << P.log2_words) < S) P.log2_words++;
@@ -455,15 +506,18 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
 }
 
 // the kernel sequence; ev != nullptr records an event before each stage and one after the last
-static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nstage, const char **names,
-                         hipEvent_t *evs = nullptr)
+// the kernel sequence for one range of images; names != nullptr records an event before each stage
+static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s, bool from_resync, int *nstage,
+                         const char **names, hipEvent_t *evs)
 {
-    if (!evs) evs = b->ev;
-    if (!b->nimg) {
-        if (nstage) *nstage = 0;
-        return HJD_OK;
-    }
-    const HjdParams &P = b->P;
+    HjdParams P = b->P;
+    P.off_chunk = r.chunk0;
+    P.off_syncwg = r.syncwg0;
+    P.off_writewg = r.writewg0;
+    P.off_img = (uint32_t)r.i0;
+    P.off_dcchunk = r.dc0;
+    P.off_group = r.group0;
+    const uint32_t nimg = (uint32_t)(r.i1 - r.i0);
     int k = 0;
     auto mark = [&](const char *name) -> int {
         if (names) {
@@ -478,30 +532,64 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     int rc;
     if (!from_resync) {
         if ((rc = mark("reset"))) return rc;
-        HIPCHK(hipMemsetAsync(b->d_st, 0, sizeof(HjdImageState) * b->nimg, s));
+        HIPCHK(hipMemsetAsync(b->d_st + r.i0, 0, sizeof(HjdImageState) * nimg, s));
         if ((rc = mark("unstuff"))) return rc;
-        if (hjd_launch_unstuff(P, b->nchunks, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_unstuff(P, r.nchunk, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_sync"))) return rc;
-        if (hjd_launch_sync(P, b->nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_repair"))) return rc;
         for (int l = 1; l < b->dec->sync_launches; l++)
-            if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+            if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
     } else {
-        if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
-        if (hjd_launch_sync(P, b->nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
     }
     if ((rc = mark("scan"))) return rc;
-    if (hjd_launch_scan(P, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_scan(P, nimg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("boff_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
-    HIPCHK(hipMemsetAsync(b->d_boff, 0, sizeof(uint32_t) * b->nboff, s));
+    HIPCHK(hipMemsetAsync(b->d_boff + r.boff0, 0, sizeof(uint32_t) * r.nboff, s));
     if ((rc = mark("huff_write"))) return rc;
-    if (hjd_launch_write(P, b->nwritewg, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
-    if (hjd_launch_dcscan(P, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_dcscan(P, r.ndc, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
-    if (hjd_launch_idct_color(P, b->ngroups, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_idct_color(P, r.ngroup, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("end"))) return rc;
     if (nstage) *nstage = k;
+    return HJD_OK;
+}
+
+// Whole batch.  With one range (default) everything goes to the caller's stream; with several, each range
+// runs on an internal stream between a fork and a join event on the caller's stream.  Stage events
+// (names != nullptr) always use the single-stream form.
+static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nstage, const char **names,
+                         hipEvent_t *evs = nullptr)
+{
+    if (!evs) evs = b->ev;
+    if (!b->nimg) {
+        if (nstage) *nstage = 0;
+        return HJD_OK;
+    }
+    if (names || b->ranges.size() <= 1) {
+        hjd_batch::Range all{};
+        all.i0 = 0;
+        all.i1 = b->nimg;
+        all.nchunk = b->nchunks;
+        all.nsyncwg = b->nsyncwg;
+        all.nwritewg = b->nwritewg;
+        all.ndc = b->ndcchunks;
+        all.ngroup = b->ngroups;
+        all.nboff = b->nboff;
+        return range_enqueue(b, all, s, from_resync, nstage, names, evs);
+    }
+    HIPCHK(hipEventRecord(b->fork_ev, s));
+    for (size_t k = 0; k < b->ranges.size(); k++) {
+        HIPCHK(hipStreamWaitEvent(b->istreams[k], b->fork_ev, 0));
+        int rc = range_enqueue(b, b->ranges[k], b->istreams[k], from_resync, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(b->join_ev[k], b->istreams[k]));
+        HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
+    }
     return HJD_OK;
 }
 

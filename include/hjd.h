@@ -109,8 +109,10 @@ typedef enum hjd_out_format {
 
 typedef struct hjd_options {
     int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..2048); 0 = default */
-    int sync_launches;   /* speculative synchronisation launches before verification; 0 = default */
-    int reserved[6];
+    int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
+    int streams;         /* internal HIP streams a batch is split over (contiguous image ranges, forked from and
+                          * joined to the caller's stream); 0 or 1 = everything on the caller's stream */
+    int reserved[5];
 } hjd_options;
 
 hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);

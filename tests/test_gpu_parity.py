@@ -259,6 +259,37 @@ def test_reference_shaped_entry_points(hjd, golden):
     assert L.hjd_last_status() == hjd.HJD_ERR_NOT_JPEG
 
 
+@pytest.mark.parametrize("streams", [2, 3, 7])
+def test_internal_streams(hjd, golden, streams):
+    """hjd_options.streams: the batch is split into contiguous image ranges on internal HIP streams,
+    forked from and joined to the caller's stream.  Same bytes, any split (including more streams than
+    images can fill evenly, failed images in between, restart and non-restart images mixed)."""
+    d = hjd.Decoder(0, streams=streams)
+    fx = _ok_fixtures(golden, restart=("none", "clean"))
+    jpgs = [f[2] for f in fx] + [b"junk", T.synth_jpeg(1000, 800, 77, 85, 2, 2), T.synth_jpeg(640, 480, 78, 85, 1, 1, 9, 7.0)]
+    for rep in range(2):
+        st, outs = d.decode(jpgs)
+        for j, s, o in zip(jpgs, st, outs):
+            if j == b"junk":
+                assert s == hjd.HJD_ERR_NOT_JPEG
+                continue
+            orc, orgb, _, _, ost = T.oracle_decode(j)
+            if ost.resyncs_dirty:
+                assert s == hjd.HJD_ERR_DIRTY_RESTART
+            else:
+                assert s == 0 and np.array_equal(o, orgb)
+    # also on a non-default caller stream
+    import torch
+    side = torch.cuda.Stream()
+    b = d.prepare(jpgs[:5])
+    b.run(side.cuda_stream)
+    assert b.finish(side.cuda_stream) == [0] * 5
+    for i in range(5):
+        assert np.array_equal(b.download(i), T.oracle_decode(jpgs[i])[1])
+    b.close()
+    d.close()
+
+
 def test_empty_and_all_bad_batches(hjd, dec):
     """Ragged inputs at the batch level: no images, and only images that fail to parse."""
     st, outs = dec.decode([])
