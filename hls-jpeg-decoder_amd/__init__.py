@@ -43,7 +43,7 @@ class JpegData(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("subseq_bits", ctypes.c_int), ("sync_launches", ctypes.c_int), ("streams", ctypes.c_int),
-                ("reserved", ctypes.c_int * 5)]
+                ("sync_overlap", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
 
 
 _lib = None
@@ -141,8 +141,8 @@ def parse_header(jpg):
 class Decoder:
     """hjd_decoder: one per (process, device)."""
 
-    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0):
-        opt = Options(subseq_bits, sync_launches, streams)
+    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0):
+        opt = Options(subseq_bits, sync_launches, streams, sync_overlap)
         self._h = lib().hjd_decoder_create(device, ctypes.byref(opt))
         if not self._h:
             raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))

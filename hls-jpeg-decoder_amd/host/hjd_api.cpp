@@ -1,6 +1,6 @@
 // hjd_api.cpp — device runtime behind the C ABI (include/hjd.h): batch layout in HBM, table
 // construction, kernel sequencing on a HIP stream, status collection.  The decode itself is the
-// kernels in csrc/hjd_kernels.hip; there is no host fallback.
+// kernels in csrc/hjd_unstuff.hip, hjd_entropy.hip and hjd_pixels.hip; there is no host fallback.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +26,23 @@
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Makes the decoder's device current for the duration of a call and puts the caller's device back
+// afterwards: a batch may be driven from a thread whose current device is another one.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        else prev = -1; // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 struct hjd_decoder {
     int device = 0;
     uint32_t subseq_bits = 1024;
@@ -37,6 +54,7 @@ struct hjd_decoder {
 
 struct hjd_batch {
     hjd_decoder *dec = nullptr;
+    int device = 0;                  // dec->device, kept here so that a batch can outlive calls on its decoder
     int n = 0;                       // images offered
     int nimg = 0;                    // images that parsed and are on the device
     std::vector<int> parse_status;   // per offered image
@@ -179,9 +197,12 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         fprintf(stderr, "hjd: no usable HIP device %d (found %d); this path has no CPU fallback\n", device, n);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) {
-        hjd_set_last_status(HJD_ERR_NO_DEVICE);
-        return nullptr;
+    {
+        DeviceGuard g(device); // only checks that the device can be made current
+        if (!g.ok) {
+            hjd_set_last_status(HJD_ERR_NO_DEVICE);
+            return nullptr;
+        }
     }
     hjd_decoder *d = new hjd_decoder();
     d->device = device;
@@ -204,6 +225,14 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
         const char *ek = getenv("HJD_SYNC_OVERLAP");
         if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) d->sync_overlap = (uint32_t)atoi(ek);
+        if (opt && opt->sync_overlap != 0) {
+            if (opt->sync_overlap < -1 || opt->sync_overlap > 48) {
+                delete d;
+                hjd_set_last_status(HJD_ERR_ARG);
+                return nullptr;
+            }
+            d->sync_overlap = opt->sync_overlap < 0 ? 0u : (uint32_t)opt->sync_overlap;
+        }
     }
     return d;
 }
@@ -243,6 +272,7 @@ static void batch_free_device(hjd_batch *b)
 extern "C" void hjd_batch_destroy(hjd_batch *b)
 {
     if (!b) return;
+    DeviceGuard g(b->device);
     batch_free_device(b);
     delete b;
 }
@@ -250,7 +280,8 @@ extern "C" void hjd_batch_destroy(hjd_batch *b)
 static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
 {
     hjd_decoder *d = b->dec;
-    HIPCHK(hipSetDevice(d->device));
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     const uint32_t S = d->subseq_bits;
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
@@ -262,9 +293,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         b->dev_index[i] = -1;
         if (b->parse_status[i] != HJD_OK) continue;
         const hjd_jpeg_data &j = parsed[i];
-        if (j.stream_len >= (1u << 28)) {
-            b->parse_status[i] = HJD_ERR_UNSUPPORTED;
-            continue;
+        {   // the same checks for parsed headers and for caller-filled structs (hjd_jpeg_decode_hw)
+            const int vst = hjd_validate_jpeg_data(&j);
+            if (vst != HJD_OK) {
+                b->parse_status[i] = vst;
+                continue;
+            }
         }
         HjdImage im;
         memset(&im, 0, sizeof(im));
@@ -339,8 +373,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.boff_off = boff_cur;
         boff_cur += (size_t)im.nblocks + 1;
         {   // record capacity: one per non-zero AC coefficient (<= 63 per block, and every AC symbol with value
-            // bits takes at least 3 bits of scan), plus the rounding of every subsequence's run to 4
-            const uint64_t by_blocks = (uint64_t)im.nblocks * 63, by_bits = (uint64_t)im.scan_len * 8 / 3;
+            // bits takes at least 2 bits of scan: a 1-bit code for (run 0, size 1) plus the value bit), plus
+            // the rounding of every subsequence's run to a whole burst
+            const uint64_t by_blocks = (uint64_t)im.nblocks * 63, by_bits = (uint64_t)im.scan_len * 8 / 2;
             const uint64_t cap = (by_blocks < by_bits ? by_blocks : by_bits) + (uint64_t)HJD_REC_RUN * im.nsub_cap + 64;
             im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~(uint32_t)(HJD_REC_RUN - 1);
         }
@@ -477,6 +512,7 @@ static hjd_batch *batch_from_parsed(hjd_decoder *d, int n, const std::vector<hjd
 {
     hjd_batch *b = new hjd_batch();
     b->dec = d;
+    b->device = d->device;
     b->n = n;
     b->out_format = out_format;
     b->parse_status = pstatus;
@@ -501,7 +537,7 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
     }
     std::vector<hjd_jpeg_data> parsed(n);
     std::vector<int> pst(n);
-    for (int i = 0; i < n; i++) pst[i] = hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]);
+    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]) : HJD_ERR_ARG;
     return batch_from_parsed(d, n, parsed, pst, out_format, status);
 }
 
@@ -596,6 +632,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
 extern "C" int hjd_batch_run(hjd_batch *b, void *hip_stream)
 {
     if (!b) return HJD_ERR_ARG;
+    DeviceGuard guard(b->device); // a non-NULL hip_stream must belong to the decoder's device
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     if ((int)b->tev_n.size() < b->tev_cap) { // timing enabled and room left: record this run's stage events
         const int r = (int)b->tev_n.size();
         int ns = 0;
@@ -609,6 +647,8 @@ extern "C" int hjd_batch_run(hjd_batch *b, void *hip_stream)
 extern "C" int hjd_batch_enable_timing(hjd_batch *b, int max_runs)
 {
     if (!b || max_runs < 0 || max_runs > 4096) return HJD_ERR_ARG;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     for (auto &v : b->tev)
         for (auto &e : v) (void)hipEventDestroy(e);
     b->tev.clear();
@@ -626,6 +666,8 @@ extern "C" int hjd_batch_enable_timing(hjd_batch *b, int max_runs)
 extern "C" int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **stage_names, int cap, int *runs)
 {
     if (!b || !stage_ms_avg || !stage_names) return -1;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return -1;
     int nout = 0, nr = 0;
     for (size_t r = 0; r < b->tev_n.size(); r++) {
         const int ns = b->tev_n[r];
@@ -649,6 +691,8 @@ extern "C" int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const
 extern "C" int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_ms, const char **stage_names, int cap)
 {
     if (!b || !stage_ms || !stage_names) return -1;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return -1;
     hipStream_t s = (hipStream_t)hip_stream;
     if (!b->have_events) {
         for (auto &e : b->ev)
@@ -673,6 +717,8 @@ extern "C" int hjd_batch_run_timed(hjd_batch *b, void *hip_stream, float *stage_
 extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
 {
     if (!b) return HJD_ERR_ARG;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)hip_stream;
     int overall = HJD_OK;
     if (b->nimg) {
@@ -688,9 +734,11 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
                 overall = HJD_ERR_INTERNAL;
                 break;
             }
-            for (auto &st : b->state) st.flags = 0;
+            // everything from k_repair onwards runs again and raises its flags again; what k_unstuff_write
+            // found (a non-RSTn marker between intervals: DIRTY) is not recomputed and must survive
+            for (auto &st : b->state) st.flags &= HJD_FLAG_DIRTY;
             b->resyncs++;
-            // keep ustream_len, clear flags
+            // keep ustream_len, nmarkers
             std::vector<HjdImageState> tmp = b->state;
             HIPCHK(hipMemcpyAsync(b->d_st, tmp.data(), sizeof(HjdImageState) * b->nimg, hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -733,6 +781,8 @@ extern "C" int hjd_batch_download(hjd_batch *b, int i, uint8_t *dst, size_t cap)
     const int di = b->dev_index[i];
     if (di < 0) return b->parse_status[i] ? b->parse_status[i] : HJD_ERR_UNSUPPORTED;
     if (cap < b->out_bytes[di]) return HJD_ERR_ARG;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     HIPCHK(hipMemcpy(dst, b->d_out + b->img[di].out_off, b->out_bytes[di], hipMemcpyDeviceToHost));
     return HJD_OK;
 }
@@ -745,6 +795,8 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     const HjdImage &im = b->img[di];
     const size_t ne = (size_t)im.nblocks * 64;
     if (elems < ne) return HJD_ERR_ARG;
+    DeviceGuard guard(b->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
     // test hook: rebuild the dense DCT[] rows from the device's sparse form (records + offsets + predicted DC)
     std::vector<uint32_t> boff(im.nblocks + 1), rec(im.rec_cap);
     std::vector<int16_t> dc(im.nblocks);
@@ -858,6 +910,13 @@ extern "C" int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int heigh
     if (!width || !height || !(hFactor == 1 || hFactor == 2 || hFactor == 4) ||
         !(vFactor == 1 || vFactor == 2 || vFactor == 4) || hFactor * vFactor > 4)
         return HJD_ERR_UNSUPPORTED; // hFactor = 0 is a SIGFPE in the reference (loadjpg.cpp:1153)
+    {   // a caller-filled struct gets the checks hjd_parse_header applies, before anything is built from it
+        const int vst = hjd_validate_jpeg_data(&j);
+        if (vst != HJD_OK) {
+            hjd_set_last_status(vst);
+            return vst;
+        }
+    }
     std::vector<uint8_t> out;
     int rc = decode_one_parsed(j, HJD_OUT_RGB, out);
     if (rc == HJD_OK) memcpy(rgb_out, out.data(), out.size());

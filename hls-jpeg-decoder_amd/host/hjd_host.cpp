@@ -34,6 +34,44 @@ extern "C" const char *hjd_status_string(int s)
 
 static inline unsigned be16(const uint8_t *p) { return ((unsigned)p[0] << 8) | p[1]; }
 
+// One DHT payload (bits[1..16], vals[]) as GenHuffCodes / BuildHuffmanTable would take it (openjpg.cpp:48-98).
+int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc)
+{
+    if (!h->defined) return HJD_ERR_UNSUPPORTED;
+    unsigned total = 0, code = 0;
+    for (int k = 1; k <= 16; k++) {
+        total += h->bits[k];
+        code += h->bits[k];
+        if (code > (1u << k)) return HJD_ERR_CORRUPT; // canonical codes must stay inside each length (GenHuffCodes :48-66)
+        code <<= 1;
+    }
+    if (total > 255) return HJD_ERR_UNSUPPORTED; // uint8_t scan index never terminates (loadjpg.cpp:350-355)
+    if (is_dc) {
+        if (h->bits[16]) return HJD_ERR_UNSUPPORTED; // DC search stops at 15 bits (loadjpg.cpp:562)
+        for (unsigned k = 0; k < total; k++)
+            if (h->vals[k] > 15) return HJD_ERR_UNSUPPORTED; // reader holds at most 2 new bytes (:468-482)
+    }
+    return HJD_OK;
+}
+
+int hjd_validate_jpeg_data(const hjd_jpeg_data *j)
+{
+    if (!j || !j->stream) return HJD_ERR_ARG;
+    if (j->stream_len == 0) return HJD_ERR_CORRUPT;
+    if (j->stream_len >= (1u << 28)) return HJD_ERR_UNSUPPORTED;
+    if (!j->width || !j->height || j->width > 65535 || j->height > 65535) return HJD_ERR_UNSUPPORTED;
+    const unsigned hf = j->hfactor, vf = j->vfactor;
+    if (!(hf == 1 || hf == 2 || hf == 4) || !(vf == 1 || vf == 2 || vf == 4) || hf * vf > 4) return HJD_ERR_UNSUPPORTED;
+    for (int c = 1; c <= 3; c++) {
+        if (j->dc_table_index[c] > 3 || j->ac_table_index[c] > 3) return HJD_ERR_ARG;
+        int st = hjd_validate_huff_spec(&j->htdc[j->dc_table_index[c]], 1);
+        if (st != HJD_OK) return st;
+        st = hjd_validate_huff_spec(&j->htac[j->ac_table_index[c]], 0);
+        if (st != HJD_OK) return st;
+    }
+    return HJD_OK;
+}
+
 // Header walk with the observable behaviour of JpegParseHeader/ParseJFIF (openjpg.cpp:371-496) on
 // the inputs the reference decodes correctly; everything it would mis-handle (SURVEY.md App. A.2,
 // App. E) is rejected with a status instead.
@@ -118,19 +156,12 @@ extern "C" int hjd_parse_header(const uint8_t *buf, size_t n, hjd_jpeg_data *o)
                 if (seglen - q < 17 + total) return HJD_ERR_CORRUPT;
                 memset(h->vals, 0, sizeof(h->vals));
                 memcpy(h->vals, seg + q + 17, total);
-                // canonical code assignment must stay inside each length (GenHuffCodes :48-66)
-                unsigned code = 0;
-                for (int k = 1; k <= 16; k++) {
-                    code += h->bits[k];
-                    if (code > (1u << k)) return HJD_ERR_CORRUPT;
-                    code <<= 1;
-                }
-                if (!(tc_th & 0xF0)) {
-                    if (h->bits[16]) return HJD_ERR_UNSUPPORTED; // DC search stops at 15 bits (loadjpg.cpp:562)
-                    for (unsigned k = 0; k < total; k++)
-                        if (h->vals[k] > 15) return HJD_ERR_UNSUPPORTED; // reader holds at most 2 new bytes (:468-482)
-                }
                 h->defined = 1;
+                const int vst = hjd_validate_huff_spec(h, !(tc_th & 0xF0));
+                if (vst != HJD_OK) {
+                    h->defined = 0;
+                    return vst;
+                }
                 q += 17 + total;
             }
             break;

@@ -112,7 +112,10 @@ typedef struct hjd_options {
     int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
     int streams;         /* internal HIP streams a batch is split over (contiguous image ranges, forked from and
                           * joined to the caller's stream); 0 or 1 = everything on the caller's stream */
-    int reserved[5];
+    int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
+                          * 0 = default (8192 bits' worth), -1 = none, 1..48 = that many.  Too little warm-up is
+                          * never wrong, only slower: hjd_batch_finish then re-synchronises from the host. */
+    int reserved[4];
 } hjd_options;
 
 hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);

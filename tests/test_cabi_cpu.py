@@ -56,6 +56,56 @@ def test_parse_rejects(hjd, golden):
     assert hjd.parse_header(bytes(bad))[0] == hjd.HJD_ERR_UNSUPPORTED
 
 
+def test_decode_hw_validates_caller_filled_tables(hjd, golden):
+    """hjd_jpeg_decode_hw takes a struct the CALLER filled (the reference's stJpegData equivalent): every
+    malformed table must be refused with a status before any table is built from it — no device needed."""
+    import copy
+    import ctypes
+    import numpy as np
+    d, _ = golden
+    data = open(os.path.join(d, "syn_250x187_420_q85.jpg"), "rb").read()
+    st, good = hjd.parse_header(data)
+    assert st == 0
+    L = hjd.lib()
+    out = np.zeros((good.height, good.width, 3), np.uint8)
+
+    def call(jd, h=None, w=None, hf=None, vf=None):
+        return L.hjd_jpeg_decode_hw(ctypes.byref(jd), h or good.height, w or good.width, hf or good.hfactor,
+                                    vf or good.vfactor, out.ctypes.data)
+
+    def variant(fn):
+        jd = hjd.JpegData()
+        ctypes.memmove(ctypes.byref(jd), ctypes.byref(good), ctypes.sizeof(jd))
+        fn(jd)
+        return jd
+
+    ok_status = call(variant(lambda j: None))
+    assert ok_status in (hjd.HJD_OK, hjd.HJD_ERR_NO_DEVICE)  # well-formed: decodes, or no GPU here
+
+    def set_idx(j):
+        j.dc_table_index[2] = 7                       # reads past htdc[4]
+    def over_total(j):
+        for k in range(1, 17):
+            j.htac[0].bits[k] = 16                    # 256 codes: uint8_t scan index of the reference never ends
+    def over_subscribed(j):
+        j.htac[1].bits[1] = 3                         # three 1-bit codes
+    def dc_sym(j):
+        j.htdc[0].vals[0] = 16                        # DC symbol = 16 extra bits
+    def dc_16bit(j):
+        j.htdc[1].bits[16] = 1
+    def undefined(j):
+        j.htac[j.ac_table_index[3]].defined = 0
+    def no_stream(j):
+        j.stream_len = 0
+    for fn, want in ((set_idx, (hjd.HJD_ERR_ARG,)), (over_total, (hjd.HJD_ERR_UNSUPPORTED, hjd.HJD_ERR_CORRUPT)),
+                     (over_subscribed, (hjd.HJD_ERR_CORRUPT,)), (dc_sym, (hjd.HJD_ERR_UNSUPPORTED,)),
+                     (dc_16bit, (hjd.HJD_ERR_UNSUPPORTED, hjd.HJD_ERR_CORRUPT)), (undefined, (hjd.HJD_ERR_UNSUPPORTED,)),
+                     (no_stream, (hjd.HJD_ERR_CORRUPT,))):
+        assert call(variant(fn)) in want, fn.__name__
+    assert call(variant(lambda j: None), hf=3) == hjd.HJD_ERR_UNSUPPORTED
+    assert call(variant(lambda j: None), w=70000) == hjd.HJD_ERR_UNSUPPORTED
+
+
 def test_sizes(hjd):
     L = hjd.lib()
     assert L.hjd_bmp_bytes(512, 512) == 786486

@@ -18,6 +18,17 @@ def _build(target_dir, so, cmd):
     return path
 
 
+class EncParams(ctypes.Structure):
+    """hje_params (tools/jpeg_enc.c)."""
+    _fields_ = [("w", ctypes.c_uint), ("h", ctypes.c_uint), ("hf", ctypes.c_uint), ("vf", ctypes.c_uint),
+                ("quality", ctypes.c_int), ("qtab", ctypes.c_void_p), ("three_dqt", ctypes.c_int),
+                ("huff_mode", ctypes.c_int), ("restart_mcus", ctypes.c_uint), ("rgb", ctypes.c_void_p),
+                ("coefs", ctypes.c_void_p)]
+
+
+HUFF_STD, HUFF_SIX_PERMUTED, HUFF_SIX_OPTIMISED, HUFF_FOUR_OPTIMISED = 0, 1, 2, 3
+
+
 def enc_lib():
     global _ENC
     if _ENC is None:
@@ -26,6 +37,8 @@ def enc_lib():
         e.hje_encode.restype = ctypes.c_size_t
         e.hje_encode.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_uint,
                                  ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t]
+        e.hje_encode_ex.restype = ctypes.c_size_t
+        e.hje_encode_ex.argtypes = [ctypes.POINTER(EncParams), ctypes.c_void_p, ctypes.c_size_t]
         e.hje_synth_rgb.restype = None
         e.hje_synth_rgb.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_double]
         _ENC = e
@@ -45,6 +58,39 @@ def encode_jpeg(rgb, quality=85, hf=2, vf=2, restart_mcus=0):
     out = np.empty(cap, np.uint8)
     n = enc_lib().hje_encode(rgb.ctypes.data, w, h, quality, hf, vf, restart_mcus, out.ctypes.data, cap)
     assert 0 < n <= cap, "encoder failed"
+    return out[:n].tobytes()
+
+
+def encode_jpeg_ex(rgb=None, quality=85, hf=2, vf=2, restart_mcus=0, three_dqt=False, huff_mode=HUFF_STD, qtab=None,
+                   coefs=None, size=None):
+    """General form of the test encoder: three DQTs (Cb and Cr quantised differently), six Huffman
+    tables (permuted Annex K or optimised per component), explicit quantiser tables (3 x 64, natural
+    order) and explicit coefficient blocks (scan order, zig-zag, [0] = DC value; `size` = (w, h))."""
+    P = EncParams()
+    keep = []
+    if coefs is not None:
+        w, h = size
+        coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+        nm = ((w + 8 * hf - 1) // (8 * hf)) * ((h + 8 * vf - 1) // (8 * vf))
+        assert coefs.shape == (nm * (hf * vf + 2), 64), coefs.shape
+        P.coefs = coefs.ctypes.data
+        keep.append(coefs)
+    else:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, _ = rgb.shape
+        P.rgb = rgb.ctypes.data
+        keep.append(rgb)
+    if qtab is not None:
+        qtab = np.ascontiguousarray(qtab, dtype=np.uint8)
+        assert qtab.shape == (3, 64)
+        P.qtab = qtab.ctypes.data
+        keep.append(qtab)
+    P.w, P.h, P.hf, P.vf, P.quality = w, h, hf, vf, quality
+    P.three_dqt, P.huff_mode, P.restart_mcus = int(three_dqt), int(huff_mode), restart_mcus
+    cap = w * h * 3 + (coefs.size * 4 if coefs is not None else 0) + 65536
+    out = np.empty(cap, np.uint8)
+    n = enc_lib().hje_encode_ex(ctypes.byref(P), out.ctypes.data, cap)
+    assert 0 < n <= cap, "encoder failed (a coefficient without a code, or bad arguments)"
     return out[:n].tobytes()
 
 
@@ -148,3 +194,28 @@ def ref_convert(jpg_path, bmp_path, big=True, timeout=600):
     assert exe, "oracle/_ref not built (make -C oracle ref; needs /root/reference)"
     return subprocess.run("ulimit -s unlimited; exec %s %s %s > /dev/null" % (exe, jpg_path, bmp_path),
                           shell=True, timeout=timeout).returncode
+
+
+# ---- reference-produced hashes for the full-size inputs (tools/make_large_golden.py) ----------------
+
+_LARGE = None
+
+
+def large_golden(w, h, seed, quality, hf, vf, jpg):
+    """Entry of tests/golden/large_manifest.json for this synthetic input, or None when there is none
+    or when the regenerated input is not byte-identical to the one the reference was run on (another
+    libm): the caller then falls back to the oracle and says so."""
+    import hashlib
+    import json
+    global _LARGE
+    if _LARGE is None:
+        p = os.path.join(ROOT, "tests", "golden", "large_manifest.json")
+        _LARGE = json.load(open(p)) if os.path.exists(p) else {}
+    ent = _LARGE.get("syn_%dx%d_s%d_q%d_%dx%d" % (w, h, seed, quality, hf, vf))
+    if ent is None:
+        return None
+    if hashlib.sha256(jpg).hexdigest() != ent["jpg_sha256"]:
+        print("large_golden: regenerated %dx%d seed %d differs from the input the reference saw; using the oracle"
+              % (w, h, seed))
+        return None
+    return ent

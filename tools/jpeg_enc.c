@@ -157,11 +157,149 @@ static void fdct_quant(const float *px /*64, level-shifted*/, const uint8_t *q, 
     }
 }
 
-static void encode_block(bw_t *w, const int16_t *zz, int *pred, const enc_tab_t *dc, const enc_tab_t *ac)
+/* ---- optimised Huffman tables (ITU T.81 Annex K.2, written from the text) ---------------- */
+
+/* freq[0..255] symbol counts -> bits[1..16], vals[] of a length-limited canonical code.  A reserved
+ * 257th symbol keeps the all-ones code unused.  maxlen = 16 (AC) or 15 (DC: the reference's DC code
+ * search stops at 15 bits, loadjpg.cpp:562). */
+static int gen_optimal_table(const long *freq_in, int maxlen, uint8_t *bits /*17*/, uint8_t *vals /*256*/)
 {
-    int diff = zz[0] - *pred;
-    *pred = zz[0];
+    long freq[257];
+    int codesize[257], others[257];
+    uint8_t cnt[64];
+    memset(cnt, 0, sizeof(cnt));
+    for (int i = 0; i < 256; i++) freq[i] = freq_in[i];
+    freq[256] = 1;
+    for (int i = 0; i < 257; i++) {
+        codesize[i] = 0;
+        others[i] = -1;
+    }
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        long v = 1000000000L;
+        for (int i = 0; i <= 256; i++)
+            if (freq[i] && freq[i] <= v) {
+                v = freq[i];
+                c1 = i;
+            }
+        v = 1000000000L;
+        for (int i = 0; i <= 256; i++)
+            if (freq[i] && freq[i] <= v && i != c1) {
+                v = freq[i];
+                c2 = i;
+            }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2];
+        freq[c2] = 0;
+        codesize[c1]++;
+        while (others[c1] >= 0) {
+            c1 = others[c1];
+            codesize[c1]++;
+        }
+        others[c1] = c2;
+        codesize[c2]++;
+        while (others[c2] >= 0) {
+            c2 = others[c2];
+            codesize[c2]++;
+        }
+    }
+    for (int i = 0; i <= 256; i++)
+        if (codesize[i]) {
+            if (codesize[i] > 63) return 0;
+            cnt[codesize[i]]++;
+        }
+    for (int i = 63; i > maxlen; i--) /* Figure K.3: move pairs of too-long codes up */
+        while (cnt[i] > 0) {
+            int j = i - 2;
+            while (j > 0 && cnt[j] == 0) j--;
+            if (j <= 0) return 0;
+            cnt[i] -= 2;
+            cnt[i - 1]++;
+            cnt[j + 1] += 2;
+            cnt[j]--;
+        }
+    {
+        int i = maxlen;
+        while (i > 0 && cnt[i] == 0) i--;
+        if (i <= 0) return 0;
+        cnt[i]--; /* the reserved code point */
+    }
+    memset(bits, 0, 17);
+    for (int i = 1; i <= 16; i++) bits[i] = cnt[i];
+    int k = 0;
+    for (int l = 1; l <= 63; l++)
+        for (int i = 0; i < 256; i++)
+            if (codesize[i] == l) vals[k++] = (uint8_t)i;
+    return k;
+}
+
+/* same code lengths, symbols handed out in a different order: still a valid prefix code for the same
+ * symbol set, and a different DHT payload (used to give Cb and Cr tables of their own) */
+static void permute_vals(const uint8_t *vals, int n, uint8_t *out, int salt)
+{
+    memcpy(out, vals, (size_t)n);
+    for (int i = 0; i + 1 < n; i += 2 + (salt & 1)) {
+        uint8_t t = out[i];
+        out[i] = out[i + 1];
+        out[i + 1] = t;
+    }
+}
+
+typedef struct hje_params {
+    unsigned w, h, hf, vf;
+    int quality;            /* libjpeg scaling of the Annex K tables, when qtab == NULL */
+    const uint8_t *qtab;    /* optional 3 x 64 quantiser tables, natural order: Y, Cb, Cr */
+    int three_dqt;          /* 1: three DQT segments (ids 0,1,2; Cb -> 1, Cr -> 2); 0: two, Cb and Cr share id 1 */
+    int huff_mode;          /* 0: the four Annex K tables; 1: six tables, Cb/Cr get permuted Annex K tables;
+                               2: six tables optimised per component; 3: four optimised tables (Y / chroma) */
+    unsigned restart_mcus;
+    const uint8_t *rgb;     /* h*w*3, when coefs == NULL */
+    const int16_t *coefs;   /* optional: blocks in scan order, 64 zig-zag values each, [0] = the DC VALUE the
+                               decoder must end up with (differences are taken here, int16 wrap) */
+} hje_params;
+
+typedef struct {
+    uint8_t bits[17];
+    uint8_t vals[256];
+    int n;
+    enc_tab_t tab;
+} huff_def_t;
+
+static void def_from(huff_def_t *d, const uint8_t *bits, const uint8_t *vals)
+{
+    memcpy(d->bits, bits, 17);
+    d->n = 0;
+    for (int l = 1; l <= 16; l++) d->n += bits[l];
+    memset(d->vals, 0, 256);
+    memcpy(d->vals, vals, (size_t)d->n);
+    make_tab(&d->tab, d->bits, d->vals);
+}
+
+static void count_block(const int16_t *zz, int diff, long *fdc, long *fac)
+{
+    fdc[nbits_of(diff)]++;
+    int run = 0;
+    for (int k = 1; k < 64; k++) {
+        int v = zz[k];
+        if (v == 0) {
+            run++;
+            continue;
+        }
+        while (run > 15) {
+            fac[0xF0]++;
+            run -= 16;
+        }
+        fac[(run << 4) | nbits_of(v)]++;
+        run = 0;
+    }
+    if (run > 0) fac[0]++;
+}
+
+/* returns 0 when a symbol has no code in the table in use */
+static int encode_block_diff(bw_t *w, const int16_t *zz, int diff, const enc_tab_t *dc, const enc_tab_t *ac)
+{
     int n = nbits_of(diff);
+    if (n > 15 || !dc->len[n]) return 0;
     put_bits(w, dc->code[n], dc->len[n]);
     if (n) put_bits(w, (unsigned)(diff < 0 ? diff - 1 : diff), n);
     int run = 0;
@@ -172,42 +310,161 @@ static void encode_block(bw_t *w, const int16_t *zz, int *pred, const enc_tab_t 
             continue;
         }
         while (run > 15) {
+            if (!ac->len[0xF0]) return 0;
             put_bits(w, ac->code[0xF0], ac->len[0xF0]);
             run -= 16;
         }
         int s = nbits_of(v);
         int rs = (run << 4) | s;
+        if (s > 15 || !ac->len[rs]) return 0;
         put_bits(w, ac->code[rs], ac->len[rs]);
         put_bits(w, (unsigned)(v < 0 ? v - 1 : v), s);
         run = 0;
     }
-    if (run > 0) put_bits(w, ac->code[0], ac->len[0]);
+    if (run > 0) {
+        if (!ac->len[0]) return 0;
+        put_bits(w, ac->code[0], ac->len[0]);
+    }
+    return 1;
 }
 
 /*
- * rgb: h*w*3 bytes.  quality 1..100 (libjpeg scaling).  hf,vf: luma sampling (chroma 1x1).
- * restart_mcus: 0 = no DRI; otherwise DRI interval in MCUs with RSTn markers.
- * Returns the number of bytes the stream needs (<= cap when it fitted), 0 on bad args.
+ * General form.  Returns the number of bytes the stream needs (<= cap when it fitted), 0 on bad
+ * arguments or when a coefficient cannot be coded with the chosen tables.
  */
-size_t hje_encode(const uint8_t *rgb, unsigned w, unsigned h, int quality, unsigned hf, unsigned vf,
-                  unsigned restart_mcus, uint8_t *out, size_t cap)
+size_t hje_encode_ex(const hje_params *P, uint8_t *out, size_t cap)
 {
+    const unsigned w = P->w, h = P->h, hf = P->hf, vf = P->vf;
     if (!w || !h || w > 65535 || h > 65535 || !hf || !vf || hf * vf > 4) return 0;
+    if (!P->rgb && !P->coefs) return 0;
     init_ct();
+    int quality = P->quality;
     if (quality < 1) quality = 1;
     if (quality > 100) quality = 100;
     int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
-    uint8_t ql[64], qc[64];
+    uint8_t qt[3][64]; /* natural order */
     for (int i = 0; i < 64; i++) {
-        int a = (QL[i] * scale + 50) / 100, b = (QC[i] * scale + 50) / 100;
-        ql[i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
-        qc[i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+        if (P->qtab) {
+            for (int c = 0; c < 3; c++) qt[c][i] = P->qtab[c * 64 + i] ? P->qtab[c * 64 + i] : 1;
+        } else {
+            int a = (QL[i] * scale + 50) / 100, b = (QC[i] * scale + 50) / 100;
+            qt[0][i] = (uint8_t)(a < 1 ? 1 : (a > 255 ? 255 : a));
+            qt[1][i] = (uint8_t)(b < 1 ? 1 : (b > 255 ? 255 : b));
+            /* a third table that differs from Cb's everywhere it can: coarser, and transposed */
+            int t = i / 8 + (i % 8) * 8;
+            int c = (QC[t] * scale * 3 / 2 + 50) / 100 + 1;
+            qt[2][i] = P->three_dqt ? (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c)) : qt[1][i];
+        }
     }
-    enc_tab_t dcl, dcc, acl, acc;
-    make_tab(&dcl, DC_L_BITS, DC_VALS);
-    make_tab(&dcc, DC_C_BITS, DC_VALS);
-    make_tab(&acl, AC_L_BITS, AC_L_VALS);
-    make_tab(&acc, AC_C_BITS, AC_C_VALS);
+    const unsigned mw = 8 * hf, mh = 8 * vf;
+    const unsigned mcux = (w + mw - 1) / mw, mcuy = (h + mh - 1) / mh;
+    const unsigned nby = hf * vf, nb = nby + 2;
+    const size_t nblocks = (size_t)mcux * mcuy * nb;
+
+    /* pass 1: all quantised blocks in scan order */
+    int16_t *cf = NULL;
+    const int16_t *C = P->coefs;
+    if (!C) {
+        cf = (int16_t *)malloc(nblocks * 64 * sizeof(int16_t));
+        float *Y = (float *)malloc(sizeof(float) * mw * mh);
+        float *Cb = (float *)malloc(sizeof(float) * mw * mh);
+        float *Cr = (float *)malloc(sizeof(float) * mw * mh);
+        if (!cf || !Y || !Cb || !Cr) {
+            free(cf); free(Y); free(Cb); free(Cr);
+            return 0;
+        }
+        float blk[64];
+        size_t bi = 0;
+        for (unsigned my = 0; my < mcuy; my++)
+            for (unsigned mx = 0; mx < mcux; mx++) {
+                for (unsigned y = 0; y < mh; y++) {
+                    unsigned sy = my * mh + y;
+                    if (sy >= h) sy = h - 1;
+                    for (unsigned x = 0; x < mw; x++) {
+                        unsigned sx = mx * mw + x;
+                        if (sx >= w) sx = w - 1;
+                        const uint8_t *p = P->rgb + ((size_t)sy * w + sx) * 3;
+                        float r = p[0], g = p[1], b = p[2];
+                        Y[y * mw + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+                        Cb[y * mw + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+                        Cr[y * mw + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+                    }
+                }
+                for (unsigned by = 0; by < vf; by++)
+                    for (unsigned bx = 0; bx < hf; bx++) {
+                        for (int y = 0; y < 8; y++)
+                            for (int x = 0; x < 8; x++) blk[y * 8 + x] = Y[(by * 8 + y) * mw + bx * 8 + x];
+                        fdct_quant(blk, qt[0], cf + 64 * bi++);
+                    }
+                for (int c = 0; c < 2; c++) {
+                    const float *src = c ? Cr : Cb;
+                    for (int y = 0; y < 8; y++)
+                        for (int x = 0; x < 8; x++) {
+                            float s = 0;
+                            for (unsigned dy = 0; dy < vf; dy++)
+                                for (unsigned dx = 0; dx < hf; dx++) s += src[(y * vf + dy) * mw + x * hf + dx];
+                            blk[y * 8 + x] = s / (float)(hf * vf);
+                        }
+                    fdct_quant(blk, qt[1 + c], cf + 64 * bi++);
+                }
+            }
+        free(Y); free(Cb); free(Cr);
+        C = cf;
+    }
+
+    /* tables: slot = component*2 + isAC */
+    huff_def_t T[6];
+    int tid[6]; /* DHT identifier (Th) of each slot */
+    if (P->huff_mode == 2 || P->huff_mode == 3) {
+        long f[6][256];
+        memset(f, 0, sizeof(f));
+        int pred[3] = {0, 0, 0};
+        unsigned mc = 0;
+        for (size_t b = 0; b < nblocks; b++) {
+            const unsigned m = (unsigned)(b % nb);
+            const int c = m < nby ? 0 : (int)(m - nby + 1);
+            if (P->restart_mcus && m == 0) {
+                if (mc && mc % P->restart_mcus == 0) pred[0] = pred[1] = pred[2] = 0;
+                mc++;
+            }
+            const int16_t *zz = C + 64 * b;
+            const int diff = (int16_t)(zz[0] - pred[c]);
+            pred[c] = zz[0];
+            const int g = P->huff_mode == 3 && c == 2 ? 1 : c; /* mode 3: Cb and Cr pooled */
+            count_block(zz, diff, f[g * 2], f[g * 2 + 1]);
+        }
+        for (int sl = 0; sl < 6; sl++) {
+            const int src = P->huff_mode == 3 && sl >= 4 ? sl - 2 : sl;
+            uint8_t bits[17], vals[256];
+            if (src != sl) {
+                T[sl] = T[src];
+                continue;
+            }
+            memset(vals, 0, sizeof(vals));
+            if (!gen_optimal_table(f[sl], (sl & 1) ? 16 : 15, bits, vals)) {
+                free(cf);
+                return 0;
+            }
+            def_from(&T[sl], bits, vals);
+        }
+    } else {
+        def_from(&T[0], DC_L_BITS, DC_VALS);
+        def_from(&T[1], AC_L_BITS, AC_L_VALS);
+        def_from(&T[2], DC_C_BITS, DC_VALS);
+        def_from(&T[3], AC_C_BITS, AC_C_VALS);
+        if (P->huff_mode == 1) {
+            uint8_t pv[256];
+            permute_vals(DC_VALS, 12, pv, 0);
+            def_from(&T[4], DC_C_BITS, pv);
+            permute_vals(AC_C_VALS, 162, pv, 1);
+            def_from(&T[5], AC_C_BITS, pv);
+        } else {
+            T[4] = T[2];
+            T[5] = T[3];
+        }
+    }
+    const int six = P->huff_mode == 1 || P->huff_mode == 2;
+    for (int sl = 0; sl < 6; sl++) tid[sl] = six ? sl / 2 : (sl < 2 ? 0 : 1);
 
     bw_t bw = {out, cap, 0, 0, 0, 0};
     bw_t *W = &bw;
@@ -221,12 +478,12 @@ size_t hje_encode(const uint8_t *rgb, unsigned w, unsigned h, int quality, unsig
     put_word(W, 1);
     put_word(W, 1);
     put_byte(W, 0); put_byte(W, 0);
-    /* DQT x2 (zig-zag order) */
-    for (int t = 0; t < 2; t++) {
+    /* DQT x2 or x3 (zig-zag order) */
+    for (int t = 0; t < (P->three_dqt ? 3 : 2); t++) {
         put_word(W, 0xFFDB);
         put_word(W, 67);
         put_byte(W, (uint8_t)t);
-        for (int k = 0; k < 64; k++) put_byte(W, (t ? qc : ql)[UNZZ[k]]);
+        for (int k = 0; k < 64; k++) put_byte(W, qt[t][UNZZ[k]]);
     }
     /* SOF0 */
     put_word(W, 0xFFC0);
@@ -237,47 +494,39 @@ size_t hje_encode(const uint8_t *rgb, unsigned w, unsigned h, int quality, unsig
     put_byte(W, 3);
     put_byte(W, 1); put_byte(W, (uint8_t)((hf << 4) | vf)); put_byte(W, 0);
     put_byte(W, 2); put_byte(W, 0x11); put_byte(W, 1);
-    put_byte(W, 3); put_byte(W, 0x11); put_byte(W, 1);
-    /* DHT x4 */
-    const uint8_t *bitsv[4] = {DC_L_BITS, AC_L_BITS, DC_C_BITS, AC_C_BITS};
-    const uint8_t *valsv[4] = {DC_VALS, AC_L_VALS, DC_VALS, AC_C_VALS};
-    const uint8_t idv[4] = {0x00, 0x10, 0x01, 0x11};
-    for (int t = 0; t < 4; t++) {
-        int n = 0;
-        for (int l = 1; l <= 16; l++) n += bitsv[t][l];
+    put_byte(W, 3); put_byte(W, 0x11); put_byte(W, (uint8_t)(P->three_dqt ? 2 : 1));
+    /* DHT x4 or x6 */
+    for (int sl = 0; sl < (six ? 6 : 4); sl++) {
         put_word(W, 0xFFC4);
-        put_word(W, (unsigned)(19 + n));
-        put_byte(W, idv[t]);
-        for (int l = 1; l <= 16; l++) put_byte(W, bitsv[t][l]);
-        for (int i = 0; i < n; i++) put_byte(W, valsv[t][i]);
+        put_word(W, (unsigned)(19 + T[sl].n));
+        put_byte(W, (uint8_t)(((sl & 1) << 4) | tid[sl]));
+        for (int l = 1; l <= 16; l++) put_byte(W, T[sl].bits[l]);
+        for (int i = 0; i < T[sl].n; i++) put_byte(W, T[sl].vals[i]);
     }
-    if (restart_mcus) {
+    if (P->restart_mcus) {
         put_word(W, 0xFFDD);
         put_word(W, 4);
-        put_word(W, restart_mcus & 0xFFFF);
+        put_word(W, P->restart_mcus & 0xFFFF);
     }
     /* SOS */
     put_word(W, 0xFFDA);
     put_word(W, 12);
     put_byte(W, 3);
-    put_byte(W, 1); put_byte(W, 0x00);
-    put_byte(W, 2); put_byte(W, 0x11);
-    put_byte(W, 3); put_byte(W, 0x11);
+    for (int c = 0; c < 3; c++) {
+        put_byte(W, (uint8_t)(c + 1));
+        put_byte(W, (uint8_t)((tid[c * 2] << 4) | tid[c * 2 + 1]));
+    }
     put_byte(W, 0); put_byte(W, 63); put_byte(W, 0);
 
-    const unsigned mw = 8 * hf, mh = 8 * vf;
-    const unsigned mcux = (w + mw - 1) / mw, mcuy = (h + mh - 1) / mh;
-    float *Y = (float *)malloc(sizeof(float) * mw * mh);
-    float *Cb = (float *)malloc(sizeof(float) * mw * mh);
-    float *Cr = (float *)malloc(sizeof(float) * mw * mh);
+    /* pass 2: entropy coding */
     int pred[3] = {0, 0, 0};
     unsigned mcu_count = 0, rst = 0;
-    int16_t zz[64];
-    float blk[64];
-
-    for (unsigned my = 0; my < mcuy; my++) {
-        for (unsigned mx = 0; mx < mcux; mx++) {
-            if (restart_mcus && mcu_count && (mcu_count % restart_mcus) == 0) {
+    int ok = 1;
+    for (size_t b = 0; b < nblocks && ok; b++) {
+        const unsigned m = (unsigned)(b % nb);
+        const int c = m < nby ? 0 : (int)(m - nby + 1);
+        if (m == 0) {
+            if (P->restart_mcus && mcu_count && (mcu_count % P->restart_mcus) == 0) {
                 flush_bits(W);
                 put_byte(W, 0xFF);
                 put_byte(W, (uint8_t)(0xD0 + (rst & 7)));
@@ -285,46 +534,33 @@ size_t hje_encode(const uint8_t *rgb, unsigned w, unsigned h, int quality, unsig
                 pred[0] = pred[1] = pred[2] = 0;
             }
             mcu_count++;
-            for (unsigned y = 0; y < mh; y++) {
-                unsigned sy = my * mh + y;
-                if (sy >= h) sy = h - 1;
-                for (unsigned x = 0; x < mw; x++) {
-                    unsigned sx = mx * mw + x;
-                    if (sx >= w) sx = w - 1;
-                    const uint8_t *p = rgb + ((size_t)sy * w + sx) * 3;
-                    float r = p[0], g = p[1], b = p[2];
-                    Y[y * mw + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
-                    Cb[y * mw + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
-                    Cr[y * mw + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
-                }
-            }
-            for (unsigned by = 0; by < vf; by++)
-                for (unsigned bx = 0; bx < hf; bx++) {
-                    for (int y = 0; y < 8; y++)
-                        for (int x = 0; x < 8; x++) blk[y * 8 + x] = Y[(by * 8 + y) * mw + bx * 8 + x];
-                    fdct_quant(blk, ql, zz);
-                    encode_block(W, zz, &pred[0], &dcl, &acl);
-                }
-            for (int c = 0; c < 2; c++) {
-                const float *src = c ? Cr : Cb;
-                for (int y = 0; y < 8; y++)
-                    for (int x = 0; x < 8; x++) {
-                        float s = 0;
-                        for (unsigned dy = 0; dy < vf; dy++)
-                            for (unsigned dx = 0; dx < hf; dx++) s += src[(y * vf + dy) * mw + x * hf + dx];
-                        blk[y * 8 + x] = s / (float)(hf * vf);
-                    }
-                fdct_quant(blk, qc, zz);
-                encode_block(W, zz, &pred[1 + c], &dcc, &acc);
-            }
         }
+        const int16_t *zz = C + 64 * b;
+        const int diff = P->coefs ? (int)(int16_t)(zz[0] - pred[c]) : zz[0] - pred[c];
+        pred[c] = zz[0];
+        ok = encode_block_diff(W, zz, diff, &T[c * 2].tab, &T[c * 2 + 1].tab);
     }
     flush_bits(W);
     put_word(W, 0xFFD9);
-    free(Y);
-    free(Cb);
-    free(Cr);
-    return bw.pos;
+    free(cf);
+    return ok ? bw.pos : 0;
+}
+
+/*
+ * rgb: h*w*3 bytes.  quality 1..100 (libjpeg scaling).  hf,vf: luma sampling (chroma 1x1).
+ * restart_mcus: 0 = no DRI; otherwise DRI interval in MCUs with RSTn markers.  Two DQT, the four
+ * Annex K Huffman tables.  Returns the number of bytes the stream needs (<= cap when it fitted), 0 on bad args.
+ */
+size_t hje_encode(const uint8_t *rgb, unsigned w, unsigned h, int quality, unsigned hf, unsigned vf,
+                  unsigned restart_mcus, uint8_t *out, size_t cap)
+{
+    hje_params P;
+    memset(&P, 0, sizeof(P));
+    P.w = w; P.h = h; P.hf = hf; P.vf = vf;
+    P.quality = quality;
+    P.restart_mcus = restart_mcus;
+    P.rgb = rgb;
+    return hje_encode_ex(&P, out, cap);
 }
 
 /* ---- deterministic synthetic content ------------------------ */

@@ -14,7 +14,13 @@ enlarged-capacity build (ref_big) is used and the manifest says so.  Recorded pe
   status             "ok" | "unsupported" | "ref_hangs"
   restart            "none" | "clean" | "dirty"   (judged by the oracle's trace)
 
-The JPEG inputs themselves are committed (encoder output is version dependent).
+The JPEG inputs themselves are committed (encoder output is version dependent): a fixture whose
+file already exists under tests/golden/ is NOT regenerated, only re-run through the reference.
+
+Round 2 added: three DQTs with Cb's table != Cr's (the reference dequantises Cb with Cr's table,
+loadjpg.cpp:984), six distinct Huffman tables (selectors 0/1/2 for Y/Cb/Cr), a crafted block set
+whose dequantised products wrap int16 (loadjpg.cpp:144-152) and saturate Clamp (:83-91), and a
+scan of 63 x (+-1) blocks coded with a 1-bit (run 0, size 1) code (2 scan bits per coefficient).
 """
 import hashlib
 import io
@@ -100,6 +106,38 @@ def main():
     fixtures.append(("flat_64x64_444_rst1_dirty.jpg", T.encode_jpeg(flat, 85, 1, 1, 1), "ok"))
     fixtures.append(("flat_64x64_420.jpg", T.encode_jpeg(flat, 85, 2, 2, 0), "ok"))
 
+    # round 2: Cb/Cr quantised differently, six Huffman tables, int16-wrap extremes, 2-bit coefficients
+    img2 = T.synth_rgb(250, 187, 31, 6.0)
+    fixtures.append(("syn_250x187_420_q85_3dqt.jpg", T.encode_jpeg_ex(img2, 85, 2, 2, 0, True, T.HUFF_STD), "ok"))
+    fixtures.append(("syn_250x187_422_q85_3dqt_6huff.jpg", T.encode_jpeg_ex(img2, 85, 2, 1, 0, True, T.HUFF_SIX_OPTIMISED), "ok"))
+    fixtures.append(("syn_96x64_444_q60_3dqt_6perm.jpg",
+                     T.encode_jpeg_ex(T.synth_rgb(96, 64, 32, 8.0), 60, 1, 1, 0, True, T.HUFF_SIX_PERMUTED), "ok"))
+    fixtures.append(("syn_250x187_420_q85_4opt_rst5.jpg", T.encode_jpeg_ex(img2, 85, 2, 2, 5, False, T.HUFF_FOUR_OPTIMISED), "ok"))
+    rng = np.random.default_rng(11)
+    nb = 16 * 6
+    co = np.zeros((nb, 64), np.int16)
+    mags = [1, 2, 127, 128, 129, 255, 256, 257, 300, 1000, 1023, 1024, 4095, 8191, 16384, 20000, 32767]
+    for b in range(nb):
+        k = rng.integers(1, 24)
+        idx = rng.choice(np.arange(1, 64), k, replace=False)
+        co[b, idx] = rng.choice(mags, k) * rng.choice([-1, 1], k)
+    co[:, 0] = rng.integers(-32000, 32001, nb).astype(np.int16)
+    qt = np.full((3, 64), 255, np.uint8)
+    qt[2, ::3] = 1
+    qt[2, 1::7] = 129
+    qt[0, 5::4] = 128
+    qt[1, :] = 7  # never used by the reference: Cb is dequantised with Cr's table
+    fixtures.append(("ext_64x64_420_int16wrap.jpg",
+                     T.encode_jpeg_ex(None, 85, 2, 2, 0, True, T.HUFF_SIX_OPTIMISED, qtab=qt, coefs=co, size=(64, 64)), "ok"))
+    nb = 8 * 6 * 3
+    co = np.zeros((nb, 64), np.int16)
+    co[:, 1:] = rng.choice([-1, 1], (nb, 63))
+    co[:, 0] = rng.integers(-200, 200, nb)
+    qt = np.full((3, 64), 3, np.uint8)
+    qt[2] = 5
+    fixtures.append(("ext_64x48_444_dense_ones.jpg",
+                     T.encode_jpeg_ex(None, 85, 1, 1, 0, True, T.HUFF_SIX_OPTIMISED, qtab=qt, coefs=co, size=(64, 48)), "ok"))
+
     # Pillow / libjpeg-turbo (optimised Huffman tables, other DQT scalings)
     img = T.synth_rgb(250, 187, 21, 6.0)
     fixtures.append(("pil_250x187_420_q85_opt.jpg", pil_jpeg(img, quality=85, subsampling="4:2:0", optimize=True), "ok"))
@@ -114,7 +152,11 @@ def main():
 
     manifest = {}
     for name, data, expect in fixtures:
-        open(os.path.join(GOLD, name), "wb").write(data)
+        path = os.path.join(GOLD, name)
+        if os.path.exists(path):
+            data = open(path, "rb").read()  # committed bytes are the fixture
+        else:
+            open(path, "wb").write(data)
         ent = {"bytes": len(data), "sha256": hashlib.sha256(data).hexdigest()}
         if expect == "unsupported":
             ent["status"] = "unsupported"  # reference crashes / prints garbage here: no golden output
