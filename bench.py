@@ -3,16 +3,24 @@
 
 One "step" = one pass of the whole hot path (unstuff, Huffman synchronise + decode, dequantise,
 IDCT, upsample, YCbCr->RGB) over one batch of JPEGs that is already resident in HBM; outputs
-stay in HBM.  One process per GPU; images are independent, so ranks share nothing on the data
-path (weak scaling: the per-GPU batch is fixed).  torch is used for the process group (barrier
-and the max-over-ranks of the elapsed time) and for the HIP stream handle only.
+stay in HBM.  One process per GPU.  ONE global batch of N x --batch images is partitioned over the
+N ranks by hls-jpeg-decoder_amd/shard.py::partition (images are independent: no collective on
+the data path; weak scaling: the per-GPU share is fixed as N grows).  torch is used for the
+process group (barrier, MAX of the elapsed time, SUM of the pixels) and the HIP stream handle only.
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself:
+the parent never touches a GPU, spawns N fresh children with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, relays rank 0's JSON line and exits non-zero if any rank failed.  Under
+`python -m torch.distributed.run ... bench.py --gpus N` the environment is already set.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -22,45 +30,99 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 1024 * 1.2   # wave-instructions/ns-free form: 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G wave-instr/s
 
 
-def cpu_baseline(jpgs, w, h):
-    """The reference's CPU path on this box's host cores, bounded sample.  kind 'reference' = the
-    compiled reference itself (oracle/_ref/ref_big, built in the build container from the reference
-    sources, single-threaded like the reference); 'port' = our C restatement (oracle/)."""
-    import hjdtools as T
-    ncores = os.cpu_count()
-    model = "unknown CPU"
+def host_cores():
+    """CPU cores this process may actually use (affinity mask and cgroup quota, whichever is smaller)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
+                return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    exe = T.ref_binary(big=True)
-    sample = jpgs[:2]
+    return "unknown CPU"
+
+
+def _ref_one(args):
+    import hjdtools as T
+    j, td, i = args
+    jp, bp = os.path.join(td, "%d.jpg" % i), os.path.join(td, "%d.bmp" % i)
+    open(jp, "wb").write(j)
+    return T.ref_convert(jp, bp, big=True, timeout=900)
+
+
+def _port_one(j):
+    import hjdtools as T
+    rc, rgb, _, _, _ = T.oracle_decode(j)
+    T.oracle_bmp(rgb)
+    return rc
+
+
+def cpu_baseline(distinct, w, h):
+    """The reference's CPU path on this box's host cores, bounded sample: (i) single thread, like
+    the reference itself, and (ii) one image per core over all usable host cores.  kind 'reference' = the
+    compiled reference (oracle/_ref/ref_big, built in the build container from the reference's sources);
+    'port' = our C restatement (oracle/) when that binary is absent."""
+    import hjdtools as T
+    from concurrent.futures import ProcessPoolExecutor
+    cores, model = host_cores(), cpu_model()
+    have_ref = T.ref_binary(big=True) is not None
+    kind = "reference" if have_ref else "port"
     with tempfile.TemporaryDirectory() as td:
-        if exe:
-            t0 = time.time()
-            for i, j in enumerate(sample):
-                jp, bp = os.path.join(td, "%d.jpg" % i), os.path.join(td, "%d.bmp" % i)
-                open(jp, "wb").write(j)
-                T.ref_convert(jp, bp, big=True, timeout=600)
-            dt = time.time() - t0
-            kind = "reference"
-        else:
-            sample = jpgs[:8]
-            t0 = time.time()
-            for j in sample:
-                rc, rgb, _, _, _ = T.oracle_decode(j)
-                T.oracle_bmp(rgb)
-            dt = time.time() - t0
-            kind = "port"
-    return {"value": round(len(sample) * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": "%d x %dx%d 4:2:0 q85 JPEG -> BMP, single thread on %s (host has %d cores), incl. file I/O"
-                      % (len(sample), w, h, model, ncores)}
+        sample = distinct[:2]
+        t0 = time.time()
+        for i, j in enumerate(sample):
+            rc = _ref_one((j, td, i)) if have_ref else _port_one(j)
+            assert rc == 0
+        dt1 = time.time() - t0
+        work = [distinct[i % len(distinct)] for i in range(cores)]
+        t0 = time.time()
+        with ProcessPoolExecutor(max_workers=cores) as ex:
+            rcs = list(ex.map(_ref_one, [(j, td, 100 + i) for i, j in enumerate(work)])) if have_ref \
+                else list(ex.map(_port_one, work))
+        dtn = time.time() - t0
+        assert all(r == 0 for r in rcs)
+    return {"value": round(len(sample) * w * h / dt1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": "%d x %dx%d 4:2:0 q85 JPEG -> BMP, single thread on %s, incl. file I/O" % (len(sample), w, h, model),
+            "all_cores": {"value": round(len(work) * w * h / dtn / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+                          "sample": "%d images, one process per core (%d usable of %d)" % (len(work), cores, os.cpu_count() or 0)}}
+
+
+def spawn_ranks(n, argv):
+    """Parent of a self-launched multi-rank run.  Touches no GPU API (the children must be able to
+    initialise their devices freshly); returns the exit code for the whole job."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print("bench: ranks failed: %s" % bad, file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
@@ -72,17 +134,23 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--quality", type=int, default=85)
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic images replicated to fill the batch")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images per GPU, replicated to fill its share")
     ap.add_argument("--subseq-bits", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=4, help="split the per-GPU batch over this many HIP streams")
+    ap.add_argument("--streams", type=int, default=4, help="split the per-GPU share over this many HIP streams")
     ap.add_argument("--internal-streams", type=int, default=0,
                     help="instead: ONE batch, split inside the library (hjd_options.streams); no per-stage timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -104,22 +172,33 @@ def main():
                 dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus
 
     import hjdtools as T
     hjd = importlib.import_module("hls-jpeg-decoder_amd")
+    shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
 
+    # ONE global batch of world x batch images, image g = synthetic source number g mod (distinct x world);
+    # every rank computes the same partition (cost = pixels) and decodes its own shard.
     W, H = args.width, args.height
-    distinct = [T.synth_jpeg(W, H, 1000 + 17 * rank + k, args.quality, 2, 2) for k in range(max(1, args.distinct))]
-    jpgs = [distinct[i % len(distinct)] for i in range(args.batch)]
+    n_global = world * args.batch
+    n_src = max(1, args.distinct) * world
+    parts_global = shard.partition([W * H] * n_global, world)
+    mine = parts_global[rank]
+    assert sorted(sum(parts_global, [])) == list(range(n_global))
+    src_ids = sorted({g % n_src for g in mine})
+    sources = {s: T.synth_jpeg(W, H, 1000 + s, args.quality, 2, 2) for s in src_ids}
+    jpgs = [sources[g % n_src] for g in mine]
 
     if args.internal_streams > 1:
         args.streams = 1
     dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=args.internal_streams)
-    # parse + H2D: inputs are resident in HBM from here on.  The per-GPU batch may be split into
+    # parse + H2D: inputs are resident in HBM from here on.  The per-GPU share may be split into
     # sub-batches that run on separate HIP streams, so that one sub-batch's latency-bound
     # synchronisation tail overlaps another's IDCT (same total work per step).
-    ns = max(1, min(args.streams, args.batch))
+    ns = max(1, min(args.streams, len(jpgs)))
     parts = [jpgs[k::ns] for k in range(ns)]
+    part_src = [[mine[i] % n_src for i in range(k, len(jpgs), ns)] for k in range(ns)]
     batches = [dec.prepare(p, hjd.OUT_RGB) for p in parts]
     for b in batches:
         assert all(s == 0 for s in b.parse_status), b.parse_status
@@ -155,6 +234,7 @@ def main():
     dt = time.perf_counter() - t0
 
     stages_all = []
+    runs = 0
     for b, sh in zip(batches, streams):
         st = b.finish(sh)
         assert all(s == 0 for s in st), st
@@ -163,44 +243,84 @@ def main():
                              "their outputs were not final inside the timed region" % b.resync_count())
         stg, runs = b.collect_timing()
         stages_all.append(stg)
-    # per-launch stage durations: average over the sub-batches' launches (each launch covers 1/ns of the batch)
-    stages = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))] \
+    # per-launch stage durations INSIDE the timed region: other streams' kernels share the GPU (overlapped)
+    stages_ovl = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))] \
         if stages_all and stages_all[0] else []
     launch_alg_bytes = alg_bytes / ns
 
-    # parity of what was just timed: compare images of the batch with the CPU oracle (checker only)
-    parity = "ok"
-    for b, p in ((batches[0], parts[0]), (batches[-1], parts[-1])):
-        i = len(p) - 1
-        rc, orgb, _, _, _ = T.oracle_decode(p[i])
-        got = b.download(i)
-        if rc != 0 or got.shape != orgb.shape or not (got == orgb).all():
-            parity = "MISMATCH"
-    if parity != "ok":
-        raise SystemExit("bench: output differs from the oracle: " + parity)
+    # the same launches once more, ALONE on the GPU (one stream, nothing beside them): kernel times proper
+    iso_acc = {}
+    iso_order = []
+    ISO_REP = 3
+    for b in batches:
+        for _ in range(ISO_REP):
+            torch.cuda.synchronize()
+            for name, ms in b.run_timed(streams[0]):
+                if name not in iso_acc:
+                    iso_acc[name] = 0.0
+                    iso_order.append(name)
+                iso_acc[name] += ms
+        assert all(s == 0 for s in b.finish(streams[0]))
+    stages_iso = [(n, iso_acc[n] / (ISO_REP * len(batches))) for n in iso_order]
 
-    shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
+    # parity of what was just timed: reference-produced hashes where the manifest has this input, else the oracle
+    parity = "ok"
+    parity_vs = set()
+    for b, p, srcs in ((batches[0], parts[0], part_src[0]), (batches[-1], parts[-1], part_src[-1])):
+        i = len(p) - 1
+        got = b.download(i)
+        ent = T.large_golden(W, H, 1000 + srcs[i], args.quality, 2, 2, p[i])
+        if ent is not None:
+            parity_vs.add("reference hash")
+            if hashlib.sha256(got.tobytes()).hexdigest() != ent["rgb_sha256"]:
+                parity = "MISMATCH"
+        else:
+            parity_vs.add("oracle")
+            rc, orgb, _, _, _ = T.oracle_decode(p[i])
+            if rc != 0 or got.shape != orgb.shape or not (got == orgb).all():
+                parity = "MISMATCH"
+    if parity != "ok":
+        raise SystemExit("bench: output differs from the reference: " + parity)
+
+    # end to end on this rank (never `value`): host JPEG bytes -> host RGB bytes through the pipelined entry point
+    e2e = None
+    if rank == 0 and not args.no_end_to_end and hasattr(dec, "decode_host_pipelined"):
+        e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
+
     dt, total_pixels = shard.agree(dt, pixels, device="cuda" if backend == "nccl" else "cpu")  # MAX of time, SUM of pixels
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total_pixels * args.steps / dt / 1e6
-        stage_ms = {n: round(ms, 4) for n, ms in stages}
-        dom = max(stages, key=lambda x: x[1]) if stages else ("none", 0.0)
-        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair (x2)", "scan": "k_scan",
-                     "huff_write": "k_write", "idct_color": "k_idct_color", "mask_clear": "hipMemsetAsync",
-                     "reset": "hipMemsetAsync"}
+        dom = max(stages_iso, key=lambda x: x[1]) if stages_iso else ("none", 0.0)
+        ovl = dict(stages_ovl)
+        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair",
+                     "scan": "k_scan", "huff_write": "k_write", "dc_scan": "k_dcsum+k_dcapply", "idct_color": "k_idct_color",
+                     "boff_clear": "hipMemsetAsync", "reset": "hipMemsetAsync"}
         achieved = launch_alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        images_per_launch = len(jpgs) // ns
+        traffic, valu = None, None
+        for fname, key in (("traffic.json", "hbm_bytes_per_launch"), ("sq_counters.json", "valu_insts_per_launch")):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get(dom[0])
-                if ent and ent.get("images_per_launch") * ns == args.batch and ent.get("width") == W and ent.get("height") == H:
-                    traffic = ent["hbm_bytes_per_launch"]
+                ent = json.load(open(os.path.join(ROOT, "profiles", fname))).get(dom[0])
+                if ent and ent.get("images_per_launch") == images_per_launch and ent.get("width") == W and ent.get("height") == H:
+                    if fname == "traffic.json":
+                        traffic = ent[key]
+                    else:
+                        valu = ent[key]
             except Exception:
-                traffic = None
+                pass
+        roof = {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel_ms_isolated": round(dom[1], 4), "kernel_ms_overlapped": round(ovl.get(dom[0], 0.0), 4),
+                "algorithmic_bytes_per_launch": int(launch_alg_bytes), "images_per_launch": images_per_launch,
+                "launches_per_step": ns,
+                "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        if valu:  # second view of the same kernel: fp32 VALU issue (wave-instructions from the committed PMC summary)
+            ginst = valu / (dom[1] * 1e-3) / 1e9
+            roof["valu"] = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                            "frac": round(ginst / VALU_PEAK_GINST, 4), "wave_insts_per_launch": valu}
         out = {
             "metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)",
             "value": round(value, 1),
@@ -214,23 +334,23 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 entropy/pixel bytes, int16 coefficients, f32 IDCT+colour (reference arithmetic)",
             "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU, resident in HBM, "
-                                   "RGB out to HBM" % (args.batch, W, H, args.quality),
-                       "images_per_gpu": args.batch, "distinct_images": len(distinct), "width": W, "height": H,
-                       "scan_bytes_per_image": scan_bytes // max(1, args.batch),
-                       "algorithmic_bytes_per_image": alg_bytes // max(1, args.batch), "parallelism": "images sharded, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(dom[1], 4), "algorithmic_bytes_per_launch": int(launch_alg_bytes),
-                         "launches_per_step": ns,
-                         "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "stage_ms": stage_ms,
+            "config": {"workload": "batch of %d synthetic %dx%d 4:2:0 q%d baseline JPEGs per GPU (one global batch of %d "
+                                   "partitioned over %d rank(s)), resident in HBM, RGB out to HBM"
+                                   % (args.batch, W, H, args.quality, n_global, world),
+                       "images_per_gpu": len(jpgs), "distinct_images": len(sources), "width": W, "height": H,
+                       "scan_bytes_per_image": scan_bytes // max(1, len(jpgs)),
+                       "algorithmic_bytes_per_image": alg_bytes // max(1, len(jpgs)), "parallelism": "images sharded, no collectives"},
+            "roofline": roof,
+            "stage_ms_isolated": {n: round(ms, 4) for n, ms in stages_iso},
+            "stage_ms_overlapped": {n: round(ms, 4) for n, ms in stages_ovl},
             "timed_runs": runs,
             "parity": parity,
+            "parity_vs": sorted(parity_vs),
         }
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(jpgs, W, H)
+            out["cpu_baseline"] = cpu_baseline([sources[s] for s in src_ids], W, H)
         print(json.dumps(out), flush=True)
 
     for b in batches:

@@ -386,6 +386,62 @@ def test_internal_streams(hjd, golden, streams):
     d.close()
 
 
+def test_two_ranks_share_one_batch(hjd, tmp_path):
+    """The N > 1 code path on the hardware at hand: two ranks (own processes, gloo on 127.0.0.1, both on device 0)
+    decode the two shards shard.partition() gives them of ONE 64-image mixed batch.  Union = every image exactly
+    once, every image bit-exact against the oracle."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rank_worker
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, rank_worker.__file__, "0", str(tmp_path / ("r%d.json" % r))], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = {}
+    for r in range(world):
+        part = json.load(open(tmp_path / ("r%d.json" % r)))
+        assert not (set(part) & set(got)), "an image was decoded by both ranks"
+        got.update(part)
+        assert 24 <= len(part) <= 40  # balanced by compressed size, not by count
+    jpgs = rank_worker.mixed_batch()
+    assert sorted(int(k) for k in got) == list(range(len(jpgs)))
+    for g, j in enumerate(jpgs):
+        orc, orgb, _, _, ost = T.oracle_decode(j)
+        if orc == 0 and ost.resyncs_dirty == 0:
+            assert got[str(g)] == hashlib.sha256(orgb.tobytes()).hexdigest(), g
+        else:
+            assert got[str(g)].startswith("status"), g
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks itself; here both on device 0
+    over gloo (rehearsal knobs).  The line must say n_gpus 2 and count both ranks' pixels."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HJD_BENCH_BACKEND="gloo", HJD_BENCH_FORCE_DEVICE="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--width", "1920", "--height", "1080", "--distinct", "2", "--streams", "2",
+                        "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["images_per_gpu"] == 8
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 16 * 1920 * 1080) / (16 * 1920 * 1080) < 0.02
+
+
 def test_empty_and_all_bad_batches(hjd, dec):
     """Ragged inputs at the batch level: no images, and only images that fail to parse."""
     st, outs = dec.decode([])

@@ -68,3 +68,27 @@ def test_partition_edge_cases():
     assert shard.partition([5], 2) == [[0], []]
     p = shard.partition([1] * 8, 8)
     assert sorted(sum(p, [])) == list(range(8)) and all(len(x) == 1 for x in p)
+
+
+def test_bench_parent_spawns_ranks_and_reports_failure():
+    """bench.py --gpus 2 without RANK in the environment: the parent (which never touches a GPU) starts two
+    ranks; in this GPU-less container each rank exits with 'needs a HIP device', and the parent must turn that
+    into a non-zero exit instead of printing a 1-GPU line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a HIP device is present: covered by the GPU test")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and r.stderr.count("needs a HIP device") == 2
+    assert "n_gpus" not in r.stdout
+    # a launcher that disagrees with --gpus is refused too
+    env2 = dict(env, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
