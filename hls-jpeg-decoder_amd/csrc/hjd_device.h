@@ -5,23 +5,29 @@
 //   ustream  : the unstuffed scans as MSB-first 32-bit words, transposed in groups of 64 subsequences
 //              (word k of subsequence i at ((i/64)*(wps+2) + k)*64 + i%64, rows extended by two words),
 //              image i at ustream_off
-//   sub      : one HjdSub per entropy-decode subsequence (fixed bit length) — synchronisation state
-//   substart : exclusive prefix sums over sub (first block index, first record index)
-//   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16; all ones =
-//              padding), every subsequence's run rounded up to HJD_REC_RUN records so that it is
-//              written in aligned bursts; boff[b] = index of block b's first record (boff[nblocks] = end)
-//   dcd/dca  : per block, the decoded DC difference / the DC value after prediction (int16)
+//   substate : one uint4 per entropy-decode subsequence (fixed bit length): the decoder state at its end
+//              (bit position, z | m << 8) and the start state that end state was computed from
+//   subcnt   : per subsequence, blocks completed inside (low 16 bits) | AC records produced inside (high 16)
+//   wgsum    : per final-pass workgroup (HJD_WRITE_WG subsequences): totals of blocks and of records
+//              (each subsequence's records rounded up to HJD_REC_RUN)
+//   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16 | (block & 127) << 22;
+//              all ones = padding), every subsequence's run rounded up to HJD_REC_RUN records so that it is
+//              written in aligned 16-byte stores
+//   blk      : one uint2 per block: x = index of the block's first record, y = the decoded DC difference
+//              (k_write), replaced in place by the DC value after prediction (k_dcapply); one extra entry
+//              per image closes the last block's record range
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan
 //   out      : RGB or BMP bytes
 #pragma once
 #include <stdint.h>
 
-#define HJD_LUT_BITS 10
+#define HJD_LUT_BITS 11
 #define HJD_LUT_SIZE (1 << HJD_LUT_BITS)
 #define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
-#define HJD_SYNC_WG 256        // threads (= subsequences) per entropy workgroup: 4 independent waves sharing the tables
+#define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
+#define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 1024      // MCUs per DC-prediction workgroup
 
@@ -35,6 +41,8 @@
 //   code length 0: the code is longer than HJD_LUT_BITS; bits 5-15 = 1 + index of the secondary
 //   table for this prefix (0 = no code has this prefix).  Secondary tables are indexed by the next
 //   HJD_SEC_BITS bits and hold entries of the same format (length 0 = no such code).
+// 11 primary bits: on the q85 bench content 1.1 % of the AC symbols are longer than 10 bits but only
+// 0.2 % longer than 11, i.e. a 64-lane wave takes the second look-up in 12 % of its steps instead of 50 %.
 #define HJD_SEC_BITS (16 - HJD_LUT_BITS)
 #define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
 #define HJD_MAX_SEC 64
@@ -62,8 +70,10 @@ struct HjdImage {
     uint32_t nsub_cap;      // capacity: ceil(scan_len*8 / subseq_bits)
     uint32_t syncwg0;       // first synchronisation workgroup (overlapped tiling)
     uint32_t nsyncwg;
-    uint32_t writewg0;      // first final-pass workgroup (256 subsequences each)
+    uint32_t writewg0;      // first final-pass workgroup (HJD_WRITE_WG subsequences each)
     uint32_t nwritewg;
+    uint32_t repwg0;        // first repair workgroup (HJD_SYNC_WG subsequences each, no overlap)
+    uint32_t nrepwg;
     uint32_t dcchunk0;      // first DC-prediction chunk
     uint32_t ndcchunk;
     uint32_t group0;        // first IDCT/colour workgroup
@@ -76,13 +86,11 @@ struct HjdImage {
     uint32_t mark_off;      // first entry of this image in the marker arrays
     uint32_t mark_cap;      // entries reserved
     uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
+    uint32_t rec_cap;       // records reserved
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
-    uint64_t blk_off;       // first entry of this image in the per-block arrays (dcd, dca)
-    uint64_t boff_off;      // first entry in boff (nblocks + 1 entries per image)
+    uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)
     uint64_t rec_off;       // first record
-    uint32_t rec_cap;       // records reserved
-    uint32_t pad0;
     uint64_t out_off;       // byte offset into out slab
     uint8_t qt[3][64];      // dequantisation tables as USED per component (Cb already holds Cr's), zig-zag order
 };
@@ -92,7 +100,7 @@ struct HjdImageState {
     uint32_t ustream_len;   // unstuffed bytes
     uint32_t flags;         // HJD_FLAG_*
     uint32_t total_blocks;  // blocks completed over all subsequences
-    uint32_t sync_iters;    // diagnostics: sum over workgroups and launches of refinement iterations
+    uint32_t sync_iters;    // diagnostics: sum over workgroups and launches of refinement rounds
     uint32_t sync_decodes;  // diagnostics: subsequence decodes executed by the synchronisation launches
     uint32_t sync_iters_max;
     uint32_t nmarkers;      // restart mode: markers (FF xx, xx != 0) found inside the scan
@@ -102,22 +110,11 @@ struct HjdImageState {
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)
 #define HJD_FLAG_NOT_CONVERGED 4u // a subsequence was decoded from a stale start state
 #define HJD_FLAG_SHORT 8u         // stream ended before all blocks were decoded
-#define HJD_FLAG_DIRTY 16u        // restart stream outside the clean-resync domain
+#define HJD_FLAG_DIRTY 16u        // restart stream outside the clean-resync domain, found while decoding
+#define HJD_FLAG_BAD_MARKER 32u   // the same verdict from the unstuff stage (a non-RSTn marker between intervals): unlike the
+                                  // decode-stage flags it is not recomputed by a host re-synchronisation and must survive it
 
-// synchronisation record of one subsequence
-struct HjdSub {
-    uint32_t e_p;    // end state: absolute bit position (>= end of this subsequence)
-    uint32_t e_zm;   // end state: z | m << 8
-    uint32_t u_p;    // start state this record was computed from
-    uint32_t u_zm;
-    uint32_t nblk;   // blocks completed inside
-    uint32_t nrec;   // AC records produced inside
-    uint32_t pad[2];
-};
-
-struct HjdSubStart {
-    uint32_t blk0;   // index of the block in progress at the subsequence start
-    uint32_t rec0;   // index of the subsequence's first record (multiple of HJD_REC_RUN)
-};
+// synchronisation record of one subsequence (substate[]): x = end state bit position (>= end of the
+// subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
-#define HJD_REC_RUN 16 // records per aligned store burst: every subsequence's run is padded to a multiple
+#define HJD_REC_RUN 4 // records per aligned 16-byte store: every subsequence's run is padded to a multiple

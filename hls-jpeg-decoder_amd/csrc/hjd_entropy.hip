@@ -1,26 +1,35 @@
 // hjd_entropy.hip — Huffman VLC decode of the scan on gfx950 (MI355X, CDNA4).
 //   k_sync    ProcessHuffmanBlock, speculative: find the decoder state at every subsequence start
-//   k_repair  the same machinery re-run only where a wave's warm-up was too short
+//   k_repair  the same machinery re-run only where a workgroup's warm-up was too short
+//   k_scan    block / record totals per final-pass workgroup
 //   k_write   ProcessHuffmanBlock, final pass: coefficients out            (loadjpg.cpp:499-863)
 //
 // The scan of a baseline JPEG is one bit-serial string.  It is cut into fixed-size SUBSEQUENCES
-// (S bits), one per lane.  Huffman streams self-synchronise: a decoder started at a wrong
-// position/state soon falls into step with the true decode.  Each lane decodes its subsequence
-// from a guessed start state, then again from the end state of its predecessor, until
-// start == predecessor's end everywhere in the workgroup.  Workgroups overlap by a few warm-up
-// subsequences, so the first owned lane of every workgroup has (with overwhelming probability)
-// the true state; k_write re-checks start == predecessor's end for EVERY subsequence across
-// workgroup borders, and the host re-synchronises if that induction step ever fails.  Outputs
-// are written only by k_write, so speculation never reaches them.
+// (S bits).  Huffman streams self-synchronise: a decoder started at a wrong position/state soon
+// falls into step with the true decode.  Every subsequence is decoded from a guessed start state,
+// then again from the end state of its predecessor, until start == predecessor's end everywhere in
+// the workgroup.  Workgroups overlap by a few warm-up subsequences, so the first owned subsequence of
+// every workgroup has (with overwhelming probability) the true state; k_write re-checks
+// start == predecessor's end for EVERY subsequence across workgroup borders, and the host
+// re-synchronises if that induction step ever fails.  Outputs are written only by k_write, so
+// speculation never reaches them.
+//
+// Rounds are workgroup-synchronous and COMPACTED: after the two dense rounds (from the guess, from the
+// predecessor) only a shrinking minority of subsequences still changes (measured on the q85 bench
+// content: 30 %, 9 %, 3 % ...).  Each round the subsequences whose start state changed are gathered
+// (__ballot + prefix over the waves) and handed to the first lanes of the workgroup, so a round with 40
+// changed subsequences costs one wave's issue slots instead of eight waves each dragging a few live
+// lanes through the whole loop (round 1's kernel spent 5.9 wave-passes per wave for 2.8 lane-passes of
+// work).  Waves without work wait at the barrier and issue nothing.
 //
 // Stream layout (written by k_unstuff_write): TRANSPOSED in groups of 64 subsequences — word k of
 // subsequence i lives at word ((i/64)*(wps+2) + k)*64 + i%64, and every row is extended by the
-// first two words of the next row — so that a wave stages its 64 rows with fully coalesced loads and
-// then reads them from LDS without bank conflicts ([k*64 + lane]).
-// LDS per workgroup: the Huffman tables (primary 10-bit tables + secondary tables for longer codes,
-// shared by its 4 waves) and each wave's rows.  Waves are independent after the table load: each wave
-// owns 64 - K subsequences plus K warm-up subsequences before them and iterates with __shfl_up /
-// __ballot.
+// first two words of the next row — so that 64 consecutive subsequences are staged with fully coalesced
+// loads.  A lane stages only a WINDOW of its row (phase_words + 2 words) into LDS ([k*64 + lane],
+// conflict-free) and decodes it before staging the next one: the decode loop touches LDS only (its
+// stores are never waited for — loads and stores share vmcnt on gfx9-class hardware), and the LDS a
+// workgroup holds is small enough for 6 waves per SIMD (round 1 parked whole rows: 45 KB per 256
+// threads, 1.4 resident waves per SIMD on average).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,7 +38,7 @@
 #include "hjd_kutil.h"
 
 struct EntropyLds {
-    const uint16_t *lut; // [nlut][1024]
+    const uint16_t *lut; // [nlut][HJD_LUT_SIZE]
     const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
 };
 
@@ -58,14 +67,10 @@ __device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp
     return dc | (ac << 16);
 }
 
-// ---- bit readers ------------------------------------------------------------------------------
+// ---- bit reader --------------------------------------------------------------------------------
 // window() = the next 32 bits; advance(n) consumes n <= 31 bits.  State: words hi, lo and sh = number
-// of unconsumed bits of hi (0..31); window = alignbit(hi, lo, sh).
-
-// Both kernels stage the wave's 64 rows in LDS first ([k*64 + lane], coalesced loads), so that the
-// loop's only vector-memory operations are k_write's record stores, which it never waits for (loads
-// and stores share one counter on gfx9-class hardware; reading the stream from L1 inside the loop
-// was measured 2x slower for k_write and no faster for k_sync).
+// of unconsumed bits of hi (0..31); window = alignbit(hi, lo, sh).  `rowp` points at word 0 of the
+// staged window of the lane's row (64 words between successive words).
 struct ReaderLds {
     uint32_t hi, lo, nxt, sh;
     const uint32_t *nx;
@@ -93,16 +98,6 @@ struct ReaderLds {
     }
 };
 
-// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
-//   WRITE = false: nblk counts blocks completed, nrec the AC records they hold      (synchronisation)
-//   WRITE = true : nblk is the absolute block index, nrec the index of the next record.  Every non-zero
-//                  AC coefficient becomes one record (value | zig-zag slot << 16: the DCT[] array of
-//                  loadjpg.cpp:499-863 in sparse form), appended to the lane's own run and stored four
-//                  at a time; boff[b] = first record of block b; DC DIFFERENCES go to dcd[] — DC
-//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcsum/k_dcapply
-// `rowp` points at word 0 of the lane's row (64 words between successive words), `row_bit0` is the
-// absolute bit position of the row's first bit.  tabY/tabCb/tabCr: byte offsets of the component's
-// (DC | AC << 16) primary tables.
 // RESTART (images with DRI): the reference resynchronises whenever its byte cursor sits on a marker
 // at a block start (loadjpg.cpp:535-550) — i.e. when a block ends inside the last data byte before
 // a marker — and between a DC code and its extra bits (loadjpg.cpp:631-640); DC predictors are NOT
@@ -114,23 +109,38 @@ struct ReaderLds {
 struct RestartCtx {
     const uint32_t *mpos; // marker bit positions of the image
     uint32_t nmark;
-    uint32_t mk;          // index of the next marker (first position > p at the start)
+    uint32_t mk;          // index of the next marker (first position > p)
     uint32_t ri_blocks;   // blocks per interval, 0 = no intervals expected
     uint32_t left;        // WRITE: blocks left in the current interval
 };
 
-template <bool WRITE, bool RESTART, class Reader>
+// WRITE: the lane's records waiting for their 16-byte store (shift register: r3 is the newest), and
+// where the outputs go.  Every subsequence's run of records starts at a multiple of HJD_REC_RUN, so
+// a full burst is one aligned global_store_dwordx4.
+struct WriteCtx {
+    uint32_t r0, r1, r2, r3;
+    uint32_t *rec;
+    uint32_t rec_cap;
+    uint2 *blk;
+    uint32_t nblocks;
+};
+
+// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
+//   WRITE = false: nblk counts blocks completed, nrec the AC records they hold      (synchronisation)
+//   WRITE = true : nblk is the absolute block index, nrec the index of the next record.  Every non-zero
+//                  AC coefficient becomes one record (value | zig-zag slot << 16 | block << 22: the DCT[]
+//                  array of loadjpg.cpp:499-863 in sparse form); blk[b] = (first record of block b, DC
+//                  DIFFERENCE) — DC prediction (loadjpg.cpp:619-667) is a prefix sum done by
+//                  k_dcsum/k_dcapply
+// `rowp` points at the staged window of the lane's row, `row_bit0` is the absolute bit position of the
+// window's first bit.  tabY/tabCb/tabCr: byte offsets of the component's (DC | AC << 16) primary tables.
+template <bool WRITE, bool RESTART>
 __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
                                             uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
                                             uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
-                                            uint32_t &nrec, uint32_t *__restrict__ rec, uint32_t rec_cap,
-                                            uint32_t *__restrict__ boff, int16_t *__restrict__ dcd, uint32_t nblocks,
-                                            uint32_t &flags, RestartCtx rc, uint32_t *s_rbuf = nullptr)
+                                            uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
-    // WRITE: s_rbuf[k * HJD_SYNC_WG] (k < HJD_REC_RUN) = this lane's records waiting for their store burst.
-    // A full burst leaves as back-to-back 16-byte stores to one aligned 32-byte piece of the record
-    // array, so that the memory side sees whole sectors instead of a trickle of partial ones.
-    Reader rd;
+    ReaderLds rd;
     rd.init(rowp, p - row_bit0);
     uint32_t mnext = 0xFFFFFFFFu;
     if (RESTART) {
@@ -141,7 +151,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
-    while (p < end && (!WRITE || nblk < nblocks)) {
+    while (p < end && (!WRITE || nblk < W.nblocks)) {
         rd.prefetch();
         const uint32_t win = rd.window();
         uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
@@ -162,29 +172,23 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             const uint32_t vb = ((win << len) >> 1) >> (31u - s);
             const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
             if (isdc) {
-                dcd[nblk] = (int16_t)val;
-                boff[nblk] = nrec;
+                W.blk[nblk] = make_uint2(nrec, (uint32_t)(int)(int16_t)val);
                 // the reference looks for a marker again between the DC code and its extra bits
                 if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
-                uint32_t w = ((uint32_t)val & 0xFFFFu) | (zw << 16);
+                uint32_t w = ((uint32_t)val & 0xFFFFu) | (zw << 16) | ((nblk & 127u) << 22);
                 if (zw > 63u) {
                     flags |= HJD_FLAG_OVERRUN;
                     w = HJD_REC_PAD;
                 }
-                const uint32_t k = nrec & (HJD_REC_RUN - 1u);
-                s_rbuf[k * HJD_SYNC_WG] = w;
-                if (k == HJD_REC_RUN - 1u) {
-                    if (nrec < rec_cap) {
-                        uint4 *dst = reinterpret_cast<uint4 *>(rec + (nrec - (HJD_REC_RUN - 1u)));
-#pragma unroll
-                        for (int g = 0; g < HJD_REC_RUN / 4; g++)
-                            dst[g] = make_uint4(s_rbuf[(4 * g) * HJD_SYNC_WG], s_rbuf[(4 * g + 1) * HJD_SYNC_WG],
-                                                s_rbuf[(4 * g + 2) * HJD_SYNC_WG], s_rbuf[(4 * g + 3) * HJD_SYNC_WG]);
-                    } else {
-                        flags |= HJD_FLAG_OVERRUN;
-                    }
+                W.r0 = W.r1;
+                W.r1 = W.r2;
+                W.r2 = W.r3;
+                W.r3 = w;
+                if ((nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u) {
+                    if (nrec < W.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - (HJD_REC_RUN - 1u))) = make_uint4(W.r0, W.r1, W.r2, W.r3);
+                    else flags |= HJD_FLAG_OVERRUN;
                 }
                 nrec++;
             }
@@ -197,7 +201,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
             nblk++;
-            if (WRITE && nblk == nblocks) boff[nblk] = nrec; // end of the last block's records
+            if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint2(nrec, 0u); // end of the last block's records
             m = (m + 1u == nb) ? 0u : m + 1u;
             pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
             tb = pair & 0xFFFFu;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         if (RESTART) {
             if (WRITE && blk_end) rc.left--;
             if ((blk_end && p + 8u > mnext) || p > mnext) {
-                if (WRITE && nblk < nblocks) {
+                if (WRITE && nblk < W.nblocks) {
                     // clean only if a whole interval of whole MCUs ends exactly here
                     const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
                     if (!clean) flags |= HJD_FLAG_DIRTY;
@@ -221,176 +225,217 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 rc.left = rc.ri_blocks;
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                if (p >= end) break; // the next window is staged by the caller
                 rd.init(rowp, p - row_bit0);
-            } else if (WRITE && blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < nblocks) {
+            } else if (WRITE && blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < W.nblocks) {
                 flags |= HJD_FLAG_DIRTY; // an interval ends here but the marker is not where the reference looks
                 rc.left = rc.ri_blocks;
             }
         }
     }
-    if (WRITE && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: padded
-        const uint32_t k = nrec & (HJD_REC_RUN - 1u);
-        if (nrec + HJD_REC_RUN - k <= rec_cap) {
-            uint4 *dst = reinterpret_cast<uint4 *>(rec + (nrec - k));
-#pragma unroll
-            for (int g = 0; g < HJD_REC_RUN / 4; g++) {
-                uint32_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = (uint32_t)(4 * g + j) < k ? s_rbuf[(4 * g + j) * HJD_SYNC_WG] : HJD_REC_PAD;
-                dst[g] = make_uint4(v[0], v[1], v[2], v[3]);
-            }
+}
+
+// One subsequence (row i of the image), window by window: stage phase_words + 2 words of the row into
+// the lane's LDS column, decode until the window's end, stage the next.  `active` lanes only.
+struct RowEnv {
+    const HjdParams *P;
+    const HjdImage *im;
+    EntropyLds L;
+    uint32_t tabY, tabCb, tabCr;
+    const uint32_t *wbase;  // the image's transposed stream
+    uint32_t *s_col;        // this lane's column of its wave's staging rows (word k at [k*64])
+    uint32_t total_bits;
+    uint32_t nmark;         // restart mode: markers found
+};
+
+template <bool WRITE>
+__device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
+                                           uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0)
+{
+    const HjdParams &P = *E.P;
+    const HjdImage &im = *E.im;
+    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
+    const uint32_t sp = i * S;
+    const uint32_t end = min(sp + S, E.total_bits);
+    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0};
+    if (im.restart && active) {
+        rc.nmark = E.nmark;
+        uint32_t lo = 0, hi = rc.nmark; // first marker past the start of this row
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rc.mpos[mid] <= sp) lo = mid + 1;
+            else hi = mid;
+        }
+        rc.mk = lo;
+    }
+    const uint32_t nph = (1u << lw) / WPP;
+    const uint32_t *src0 = row_base(E.wbase, i, lw);
+    for (uint32_t ph = 0; ph < nph; ph++) {
+        const uint32_t bit0 = sp + ph * WPP * 32u;
+        const uint32_t pend = min(bit0 + WPP * 32u, end);
+        const bool go = active && p < pend && (!WRITE || nblk < W.nblocks);
+        if (go) {
+            const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
+            for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
+            if (im.restart) decode_span<WRITE, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
+            else decode_span<WRITE, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
         }
     }
 }
 
 // ---- stage 1: synchronisation ----------------------------------------------------------------
-// mode 0: wave w of an image owns subsequences [w*Q, (w+1)*Q), Q = 64 - K, and additionally decodes
-//         the K subsequences before them as warm-up (their records belong to wave w-1).
-// mode 1: re-synchronisation (host fallback): 64 owned subsequences per wave, records reloaded,
-//         lane 0 takes its start from the previous wave's last record.
+// MODE 0: workgroup w of an image owns subsequences [w*Q, (w+1)*Q), Q = HJD_SYNC_WG - K, and additionally
+//         decodes the K subsequences before them as warm-up (their records belong to workgroup w-1).
+// MODE 1: repair / host re-synchronisation: HJD_SYNC_WG owned subsequences per workgroup, records reloaded,
+//         slot 0 takes its start from the previous workgroup's last record.  Returns at once (before the
+//         tables are even loaded) when every start state already equals its predecessor's end.
 
-template <int mode>
+template <int MODE>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    constexpr uint32_t T = HJD_SYNC_WG;
 
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t bid = blockIdx.x + (mode == 0 ? P.off_syncwg : P.off_writewg);
-    const int ii = mode == 0 ? find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.syncwg0; })
-                             : find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
+    const int ii = MODE == 0 ? find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.syncwg0; })
+                             : find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.repwg0; });
     const HjdImage &im = P.img[ii];
-    const uint32_t wv = (bid - (mode == 0 ? im.syncwg0 : im.writewg0)) * (HJD_SYNC_WG / 64) + (threadIdx.x >> 6);
-    const uint32_t K = mode == 0 ? P.sync_overlap : 0u, Q = 64u - K;
-    const uint32_t own0 = wv * Q, own1 = own0 + Q;
+    const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
+    const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
+    const uint32_t own0 = wg * Q, own1 = own0 + Q;
     const uint32_t row0 = own0 >= K ? own0 - K : 0u;
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = row0 + lane;
+    const uint32_t i = row0 + tid;
     const bool valid = i < nsub && i < own1;
     const bool owned = valid && i >= own0;
     const uint32_t g = im.sub0 + i;
 
-    if (mode != 0) {
-        // repair pass: nothing to do unless some record's start differs from its predecessor's end
-        bool need = false;
-        if (valid && i > 0) {
-            const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
-            const HjdSub r = P.sub[g];
-            need = pe.x != r.u_p || pe.y != r.u_zm;
-        }
-        if (!__syncthreads_or(need ? 1 : 0)) return;
-    }
-
+    // LDS: tables | per-slot state (end state, counts, work list) | staging windows
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
+    uint32_t *s_ep = s_dyn + P.lds_state_word;
+    uint32_t *s_ezm = s_ep + T;
+    uint32_t *s_cnt = s_ezm + T;
+    uint32_t *s_lp = s_cnt + T;   // work list: start bit position ...
+    uint32_t *s_lzm = s_lp + T;   // ... start z | m << 8 | slot << 16
+    uint32_t *s_wc = s_lzm + T;   // dirty subsequences per wave
+    uint32_t *s_rows = s_wc + 16;
     const HjdTableSet *ts = &P.tabs[im.tabset];
-    load_tables(ts, s_lut, s_sec);
-    const EntropyLds L = {s_lut, s_sec};
-    const uint32_t tabY = table_pair(ts->slot_pack, 0), tabCb = table_pair(ts->slot_pack, 1), tabCr = table_pair(ts->slot_pack, 2);
-    const uint32_t lw = P.log2_words;
+
+    RowEnv E;
+    E.P = &P;
+    E.im = &im;
+    E.L = {s_lut, s_sec};
+    E.tabY = table_pair(ts->slot_pack, 0);
+    E.tabCb = table_pair(ts->slot_pack, 1);
+    E.tabCr = table_pair(ts->slot_pack, 2);
+    E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
+    E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
+    E.total_bits = total_bits;
+    E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
 
     const uint32_t sp = i * S;
-    const uint32_t end = min(sp + S, total_bits);
-    const uint32_t nby = im.nby, nb = im.nb;
-    // stage this wave's 64 rows [row0, row0+64): they straddle at most two 64-row groups of the stream
-    const uint32_t rowwords = ((1u << lw) + 2u) * 64u;
-    uint32_t *s_rows = s_dyn + P.lds_stream_word + (threadIdx.x >> 6) * rowwords;
-    {
-        const uint32_t *wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
-        const uint32_t *src = row_base(wbase, i, lw);
-        if (valid) // a lane only ever reads its own row
-            for (uint32_t k = 0; k < (1u << lw) + 2u; k++) s_rows[k * 64u + lane] = src[k * 64u];
-    }
-    const uint32_t *rowp = s_rows + lane;
+    uint32_t up = sp, uzm = 0;            // start state this slot's record was computed from (home lane's registers)
+    uint32_t ext_p = sp, ext_zm = 0;      // start state offered to slot 0 from outside the workgroup
+    uint32_t flags = 0, ndec_total = 0;
+    WriteCtx W = {};
 
-    uint32_t up = sp, uzm = 0, ep = sp, ezm = 0, nblk = 0, nrec = 0, flags = 0;
-    uint32_t ext_p = sp, ext_zm = 0; // start state offered to lane 0 from outside the wave
-    RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
-    if (im.restart && valid) {
-        rc0.nmark = min(P.st[ii].nmarkers, im.mark_cap);
-        uint32_t lo = 0, hi = rc0.nmark; // first marker past the start of this row
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rc0.mpos[mid] <= sp) lo = mid + 1;
-            else hi = mid;
+    if (MODE == 0) {
+        load_tables(ts, s_lut, s_sec);
+        __syncthreads();
+        // round 0: every subsequence from the guess (bit = its first bit, z = 0, MCU phase 0)
+        uint32_t p = sp, z = 0, m = 0, nblk = 0, nrec = 0;
+        decode_row<false>(E, valid, i, p, z, m, nblk, nrec, W, flags, 0u);
+        s_ep[tid] = p;
+        s_ezm[tid] = z | (m << 8);
+        s_cnt[tid] = nblk | (nrec << 16);
+        ndec_total = min(own1, nsub) > row0 ? min(own1, nsub) - row0 : 0u;
+    } else {
+        uint4 r = make_uint4(sp, 0u, sp, 0u);
+        uint32_t c = 0;
+        if (valid) {
+            r = P.substate[g];
+            c = P.subcnt[g];
         }
-        rc0.mk = lo;
-    }
-    uint32_t ndec = 0;
-    __syncthreads(); // tables are in LDS; from here on the waves run independently
-
-    if (valid) {
-        if (mode == 0) {
-            uint32_t p = sp, z = 0, m = 0;
-            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
-            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
-            ep = p;
-            ezm = z | (m << 8);
-            ndec = 1;
-        } else {
-            const HjdSub r = P.sub[g];
-            ep = r.e_p;
-            ezm = r.e_zm;
-            up = r.u_p;
-            uzm = r.u_zm;
-            nblk = r.nblk;
-            nrec = r.nrec;
-            if (lane == 0 && i > 0) {
-                const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
-                if (pe.x >= sp && pe.x < sp + 32u) { // a record of this run always ends inside the next word
-                    ext_p = pe.x;
-                    ext_zm = pe.y;
-                }
+        s_ep[tid] = r.x;
+        s_ezm[tid] = r.y;
+        s_cnt[tid] = c;
+        up = r.z;
+        uzm = r.w;
+        ext_p = up;
+        ext_zm = uzm;
+        if (tid == 0 && valid && i > 0) {
+            const uint4 pe = P.substate[g - 1];
+            if (pe.x >= sp && pe.x < sp + 32u) { // a record's end always lies inside the next word
+                ext_p = pe.x;
+                ext_zm = pe.y;
             }
         }
     }
+    __syncthreads();
 
-    uint32_t iters = 0;
-    for (; iters <= 64u; iters++) {
-        uint32_t wp = __shfl_up(ep, 1, 64), wzm = __shfl_up(ezm, 1, 64);
-        if (lane == 0) {
-            wp = ext_p;
-            wzm = ext_zm;
-        }
+    uint32_t rounds = 0;
+    bool tables_loaded = MODE == 0;
+    for (; rounds < 96u; rounds++) {
+        // start state every slot should have: its predecessor's current end state
+        uint32_t wp = tid ? s_ep[tid - 1] : ext_p, wzm = tid ? s_ezm[tid - 1] : ext_zm;
         if (i == 0) {
             wp = 0;
             wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
         }
-        const bool changed = valid && (wp != up || wzm != uzm);
-        if (!__ballot(changed)) break;
-        if (iters == 1) __builtin_amdgcn_s_setprio(2); // chain tails are the critical path: let them issue first
-        if (changed) {
-            uint32_t p = wp, z = wzm & 0xFF, m = wzm >> 8;
-            nblk = 0;
-            nrec = 0;
-            if (im.restart) decode_span<false, true, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
-            else decode_span<false, false, ReaderLds>(L, rowp, sp, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, nullptr, 0, nullptr, nullptr, 0, flags, rc0);
-            ep = p;
-            ezm = z | (m << 8);
+        const bool dirty = valid && (wp != up || wzm != uzm);
+        const unsigned long long bal = __ballot(dirty);
+        if (lane == 0) s_wc[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t base = 0, ndirty = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < T / 64; q++) {
+            const uint32_t c = s_wc[q];
+            base += q < wv ? c : 0u;
+            ndirty += c;
+        }
+        if (ndirty == 0) break;
+        if (MODE != 0 && !tables_loaded) {
+            load_tables(ts, s_lut, s_sec);
+            tables_loaded = true;
+        }
+        if (dirty) {
+            const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            s_lp[t] = wp;
+            s_lzm[t] = wzm | (tid << 16);
             up = wp;
             uzm = wzm;
-            ndec++;
         }
+        __syncthreads();
+        if (wv * 64u < ndirty) { // waves without work go straight to the barrier
+            const bool work = tid < ndirty;
+            const uint32_t e = work ? s_lzm[tid] : 0u;
+            const uint32_t slot = e >> 16;
+            uint32_t p = work ? s_lp[tid] : 0u, z = e & 0xFFu, m = (e >> 8) & 0xFFu, nblk = 0, nrec = 0;
+            decode_row<false>(E, work, row0 + slot, p, z, m, nblk, nrec, W, flags, 0u);
+            if (work) {
+                s_ep[slot] = p;
+                s_ezm[slot] = z | (m << 8);
+                s_cnt[slot] = nblk | (nrec << 16);
+            }
+        }
+        ndec_total += ndirty;
+        __syncthreads();
     }
 
+    if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
     if (owned) {
-        HjdSub r;
-        r.e_p = ep;
-        r.e_zm = ezm;
-        r.u_p = up;
-        r.u_zm = uzm;
-        r.nblk = nblk;
-        r.nrec = nrec;
-        r.pad[0] = r.pad[1] = 0;
-        P.sub[g] = r;
+        P.substate[g] = make_uint4(s_ep[tid], s_ezm[tid], up, uzm);
+        P.subcnt[g] = s_cnt[tid];
     }
-    // diagnostics
-    atomicAdd(&P.st[ii].sync_decodes, ndec);
-    if (lane == 0) {
-        atomicAdd(&P.st[ii].sync_iters, iters);
-        atomicMax(&P.st[ii].sync_iters_max, iters);
+    if (tid == 0) { // diagnostics
+        atomicAdd(&P.st[ii].sync_decodes, ndec_total);
+        atomicAdd(&P.st[ii].sync_iters, rounds);
+        atomicMax(&P.st[ii].sync_iters_max, rounds);
     }
 }
 
@@ -399,76 +444,119 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P) { sync_body<0
 // the repair pass is its own kernel symbol so that profiles tell the two apart
 __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair(HjdParams P) { sync_body<1>(P); }
 
-// ---- stage 3: final entropy decode, coefficients out ------------------------------------------
+// ---- stage 2: totals per final-pass workgroup ---------------------------------------------------
+// k_write places its outputs by exclusive prefix sums over the subsequences' block and record counts;
+// the sums over everything BEFORE a workgroup come from these per-workgroup totals.
 
-__global__ __launch_bounds__(HJD_SYNC_WG) void k_write(HjdParams P)
+__global__ __launch_bounds__(HJD_WRITE_WG) void k_scan(HjdParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-
+    __shared__ uint32_t s_w[17];
     const uint32_t bid = blockIdx.x + P.off_writewg;
     const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
     const HjdImage &im = P.img[ii];
+    const uint32_t S = P.subseq_bits;
+    const uint32_t nsub = (P.st[ii].ustream_len * 8u + S - 1) / S;
+    const uint32_t i = (bid - im.writewg0) * HJD_WRITE_WG + threadIdx.x;
+    const uint32_t c = i < nsub ? P.subcnt[im.sub0 + i] : 0u;
+    uint32_t tb, tr;
+    block_excl_scan(c & 0xFFFFu, s_w, &tb);
+    block_excl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tr); // every run is stored in whole bursts
+    if (threadIdx.x == 0) {
+        P.wgsum[bid] = make_uint2(tb, tr);
+        if (bid == im.writewg0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
+    }
+}
+
+// ---- stage 3: final entropy decode, coefficients out ------------------------------------------
+
+__global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t bid = blockIdx.x + P.off_writewg;
+    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
+    const HjdImage &im = P.img[ii];
+    const uint32_t wg = bid - im.writewg0;
 
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
+    uint32_t *s_w = s_dyn + P.lds_state_word;
+    uint32_t *s_rows = s_w + 32;
     const HjdTableSet *ts = &P.tabs[im.tabset];
-    load_tables(ts, s_lut, s_sec);
-    const EntropyLds L = {s_lut, s_sec};
-    const uint32_t tabY = table_pair(ts->slot_pack, 0), tabCb = table_pair(ts->slot_pack, 1), tabCr = table_pair(ts->slot_pack, 2);
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = (bid - im.writewg0) * HJD_SYNC_WG + threadIdx.x;
-    // stage this wave's group of 64 rows: (wps+2) x 256 contiguous bytes of the transposed stream
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t rowwords = ((1u << P.log2_words) + 2u) * 64u;
-    uint32_t *s_rows = s_dyn + P.lds_stream_word + wv * rowwords;
-    uint32_t *s_rbuf = s_dyn + P.lds_stream_word + (HJD_SYNC_WG / 64) * rowwords + threadIdx.x;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(
-            row_base(reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off), i & ~63u, P.log2_words));
-        uint4 *dst = reinterpret_cast<uint4 *>(s_rows);
-        for (uint32_t q = lane; q < rowwords / 4; q += 64) dst[q] = src[q];
-    }
-    __syncthreads();
-    if (i >= nsub) return;
-    const uint32_t g = im.sub0 + i;
-    const uint32_t end = min(i * S + S, total_bits);
-    const uint32_t *rowp = s_rows + lane;
+    if (wg * HJD_WRITE_WG >= nsub) return; // capacity-based grid: nothing in this workgroup
+    load_tables(ts, s_lut, s_sec);
 
-    uint32_t p = 0, zm = 0;
-    if (i > 0) {
-        const uint2 pe = *reinterpret_cast<const uint2 *>(&P.sub[g - 1]);
-        p = pe.x;
-        zm = pe.y;
+    const uint32_t i = wg * HJD_WRITE_WG + tid;
+    const bool valid = i < nsub;
+    const uint32_t g = im.sub0 + i;
+
+    // where this subsequence's blocks and records go: totals of the workgroups before this one + scan inside
+    const uint32_t c = valid ? P.subcnt[g] : 0u;
+    uint32_t pb = 0, pr = 0;
+    for (uint32_t k = tid; k < wg; k += HJD_WRITE_WG) {
+        const uint2 t = P.wgsum[im.writewg0 + k];
+        pb += t.x;
+        pr += t.y;
     }
+    uint32_t base_b, base_r, tot_b, tot_r;
+    block_excl_scan(pb, s_w, &base_b);
+    block_excl_scan(pr, s_w, &base_r);
+    uint32_t blk = base_b + block_excl_scan(c & 0xFFFFu, s_w, &tot_b);
+    uint32_t nrec = base_r + block_excl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
     uint32_t flags = 0;
-    const HjdSub me = P.sub[g];
-    if (me.u_p != p || me.u_zm != zm || p < i * S || p >= i * S + 32u)
-        flags |= HJD_FLAG_NOT_CONVERGED; // induction step failed: host re-synchronises
-    const HjdSubStart st = P.substart[g];
-    uint32_t z = zm & 0xFF, m = zm >> 8, blk = st.blk0, nrec = st.rec0;
-    if (!(flags & HJD_FLAG_NOT_CONVERGED)) {
-        RestartCtx rc0 = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u};
-        if (im.restart) {
-            rc0.nmark = min(P.st[ii].nmarkers, im.mark_cap);
-            uint32_t lo = 0, hi = rc0.nmark;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rc0.mpos[mid] <= i * S) lo = mid + 1;
-                else hi = mid;
-            }
-            rc0.mk = lo;
-            rc0.left = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
-            decode_span<true, true, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                               nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
-                                               P.dcd + im.blk_off, im.nblocks, flags, rc0, s_rbuf);
-        } else {
-            decode_span<true, false, ReaderLds>(L, rowp, i * S, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, end, blk,
-                                                nrec, P.rec + im.rec_off, im.rec_cap, P.boff + im.boff_off,
-                                                P.dcd + im.blk_off, im.nblocks, flags, rc0, s_rbuf);
+    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub) { // the workgroup that holds the last subsequence
+        P.st[ii].total_blocks = base_b + tot_b;
+        if (base_b + tot_b < im.nblocks) flags |= HJD_FLAG_SHORT;
+    }
+
+    RowEnv E;
+    E.P = &P;
+    E.im = &im;
+    E.L = {s_lut, s_sec};
+    E.tabY = table_pair(ts->slot_pack, 0);
+    E.tabCb = table_pair(ts->slot_pack, 1);
+    E.tabCr = table_pair(ts->slot_pack, 2);
+    E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
+    E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
+    E.total_bits = total_bits;
+    E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
+
+    // induction step: this subsequence's record must have been computed from its predecessor's end state
+    uint32_t p = 0, zm = 0;
+    bool go = valid;
+    if (valid) {
+        if (i > 0) {
+            const uint4 pe = P.substate[g - 1];
+            p = pe.x;
+            zm = pe.y;
         }
+        const uint4 me = P.substate[g];
+        if (me.z != p || me.w != zm || p < i * S || p >= i * S + 32u) {
+            flags |= HJD_FLAG_NOT_CONVERGED; // host re-synchronises
+            go = false;
+        }
+    }
+    __syncthreads(); // tables are in LDS
+
+    uint32_t z = zm & 0xFFu, m = zm >> 8;
+    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks};
+    const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
+    decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0);
+    if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
+        const uint32_t k = nrec & (HJD_REC_RUN - 1u);
+        for (uint32_t q = k; q < HJD_REC_RUN; q++) {
+            W.r0 = W.r1;
+            W.r1 = W.r2;
+            W.r2 = W.r3;
+            W.r3 = HJD_REC_PAD;
+        }
+        if (nrec + HJD_REC_RUN - k <= im.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - k)) = make_uint4(W.r0, W.r1, W.r2, W.r3);
+        else flags |= HJD_FLAG_OVERRUN;
     }
     if (flags) atomicOr(&P.st[ii].flags, flags);
 }
@@ -487,12 +575,20 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 {
     if (!nwg) return 0;
     if (mode == 0) {
-        if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes)) return -1;
-        hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P);
+        if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
+        hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     } else {
-        if (set_dyn_lds(reinterpret_cast<const void *>(k_repair), P.lds_bytes)) return -1;
-        hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes, s, P);
+        if (set_dyn_lds(reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
+        hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     }
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s)
+{
+    if (!nwritewg) return 0;
+    hipLaunchKernelGGL(k_scan, dim3(nwritewg), dim3(HJD_WRITE_WG), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }
@@ -500,9 +596,8 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
 {
     if (!nwg) return 0;
-    const uint32_t lds = P.lds_bytes + HJD_REC_RUN * HJD_SYNC_WG * 4; // + the record bursts in waiting
-    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), lds)) return -1;
-    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_SYNC_WG), lds, s, P);
+    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), P.lds_bytes_write)) return -1;
+    hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_WRITE_WG), P.lds_bytes_write, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -1,4 +1,4 @@
-// hjd_kernels.h — kernel argument bundle and launch entry points (host <-> hjd_kernels.hip).
+// hjd_kernels.h — kernel argument bundle and launch entry points (host <-> csrc/*.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,31 +15,31 @@ struct HjdParams {
     uint32_t *chunk_mark;      // markers per unstuff chunk (restart mode)
     uint32_t *mpos;            // marker bit positions
     uint8_t *mval;             // marker codes
-    HjdSub *sub;               // per subsequence
-    HjdSubStart *substart;     // per subsequence
+    uint4 *substate;           // per subsequence: end state, start state used
+    uint32_t *subcnt;          // per subsequence: blocks | records << 16
+    uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
-    uint32_t *boff;            // per block: index of its first record
-    int16_t *dcd;              // DC differences, one per block (block index = blk_off + b)
-    int16_t *dca;              // DC values after prediction
+    uint2 *blk;                // per block: first record index, DC (difference, then value)
     uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences
     uint32_t ndcchunks;
     uint8_t *out;              // RGB / BMP bytes
     int nimg;
     // A launch may cover only a contiguous range of images (sub-batches on separate streams): these are
     // added to blockIdx.x so that every kernel still sees batch-global workgroup / image numbers.
-    uint32_t off_chunk, off_syncwg, off_writewg, off_img, off_dcchunk, off_group;
+    uint32_t off_chunk, off_syncwg, off_repwg, off_writewg, off_img, off_dcchunk, off_group;
     uint32_t subseq_bits;      // power of two, 64..2048
     uint32_t log2_words;       // log2(subseq_bits / 32)
-    uint32_t sync_overlap;     // warm-up subsequences shared with the previous synchronisation workgroup
-    uint32_t lds_lut_word;     // entropy kernels' dynamic LDS: word offset of the primary tables
-    uint32_t lds_sec_word;     //                               word offset of the secondary tables
-    uint32_t lds_stream_word;  //                               word offset of k_write's staged rows (= table bytes / 4)
-    uint32_t lds_bytes;        //                               total bytes (k_write)
+    uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
+    uint32_t phase_words;      // words of a subsequence staged in LDS at a time (power of two, <= subseq_bits / 32)
+    uint32_t lds_sec_word;     // entropy kernels' dynamic LDS: word offset of the secondary tables
+    uint32_t lds_state_word;   //                               word offset of the per-workgroup state arrays
+    uint32_t lds_bytes_sync;   //                               total bytes, k_sync / k_repair
+    uint32_t lds_bytes_write;  //                               total bytes, k_write
 };
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
-int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int launch_idx, hipStream_t s);
-int hjd_launch_scan(const HjdParams &P, uint32_t nimg, hipStream_t s);
+int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s);
+int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s);
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

@@ -97,11 +97,15 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     // mask.  int16 wrap of the product as the reference's (short)(int) cast.
     {
         const uint32_t *rec = P.rec + im.rec_off;
-        const uint32_t *boff = P.boff + im.boff_off + b0;
-        if (tid <= KB) s_boff[tid] = min(boff[tid], im.rec_cap);
+        const uint2 *binfo = P.blk + im.blk_off + b0; // (first record, predicted DC) per block
+        uint2 bi = make_uint2(0u, 0u);
+        if (tid <= KB) {
+            bi = binfo[tid];
+            s_boff[tid] = min(bi.x, im.rec_cap);
+        }
         if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0
             const uint32_t comp = s_comp[tid];
-            const int16_t nat = (int16_t)((int)P.dca[im.blk_off + b0 + tid] * (int)s_qt[comp][0]);
+            const int16_t nat = (int16_t)((int)(int16_t)bi.y * (int)s_qt[comp][0]);
             s_coef[tid][0] = nat;
             s_mask[tid] = nat != 0 ? 1ull : 0ull;
         }

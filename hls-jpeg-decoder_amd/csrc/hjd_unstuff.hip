@@ -1,7 +1,6 @@
 // hjd_unstuff.hip — byte-level preparation of the scan and the prefix sums between the two
 // entropy passes (gfx950).
 //   k_unstuff_count / k_unstuff_write  bit-reader byte rule FF00 -> FF      (loadjpg.cpp:468-482)
-//   k_scan                             block and record index at every subsequence start
 //   k_dcsum / k_dcapply                DC prediction as a prefix sum          (loadjpg.cpp:619-667, :1159-1162)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
             // anything but RSTn between the intervals: the reference would take it for a resync point too,
             // with results no standard stream defines (what follows the last interval — EOI, padding —
             // is never looked at again)
-            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7)) atomicOr(&P.st[ii].flags, HJD_FLAG_DIRTY);
+            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7)) atomicOr(&P.st[ii].flags, HJD_FLAG_BAD_MARKER);
             mk++;
         }
         if (mask & (1u << j)) {
@@ -167,58 +166,25 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     }
 }
 
-// ---- stage 2: prefix sums over subsequences ---------------------------------------------------
-// index of the block in progress and of the first record at every subsequence start
-
-__global__ __launch_bounds__(1024) void k_scan(HjdParams P)
-{
-    __shared__ uint32_t s_w[17];
-    const int ii = (int)(blockIdx.x + P.off_img);
-    const HjdImage &im = P.img[ii];
-    const uint32_t S = P.subseq_bits;
-    const uint32_t total_bits = P.st[ii].ustream_len * 8u;
-    const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t per = (nsub + blockDim.x - 1) / blockDim.x;
-    const uint32_t lo = min(threadIdx.x * per, nsub), hi = min(lo + per, nsub);
-    uint32_t a = 0, r = 0;
-    for (uint32_t k = lo; k < hi; k++) {
-        a += P.sub[im.sub0 + k].nblk;
-        r += (P.sub[im.sub0 + k].nrec + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u); // every run is stored in whole bursts
-    }
-    uint32_t ta, tr;
-    a = block_excl_scan(a, s_w, &ta);
-    r = block_excl_scan(r, s_w, &tr);
-    for (uint32_t k = lo; k < hi; k++) {
-        HjdSubStart s;
-        s.blk0 = a;
-        s.rec0 = r;
-        P.substart[im.sub0 + k] = s;
-        a += P.sub[im.sub0 + k].nblk;
-        r += (P.sub[im.sub0 + k].nrec + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
-    }
-    if (threadIdx.x == 0) {
-        P.st[ii].total_blocks = ta;
-        if (ta < im.nblocks) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT);
-    }
-}
-
 // ---- stage 3b: DC prediction --------------------------------------------------------------------
 // DCT[0] = diff + previousDC per component, predictors zeroed once per image and never reset
 // (loadjpg.cpp:619-667, :1159-1162), int16 wrap (loadjpg.cpp:664-665) = prefix sums mod 2^16 over the
 // blocks of each component in decode order.  Two passes over chunks of HJD_DC_CHUNK MCUs:
 // k_dcsum (per-chunk totals), k_dcapply (totals of the earlier chunks + scan inside the chunk).
+// The differences sit in blk[].y (written by k_write) and are replaced IN PLACE by the predicted values,
+// so that the IDCT kernel reads one 8-byte entry per block (first record, DC).
 
 #define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
 
-__device__ __forceinline__ void dc_thread_sums(const int16_t *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+__device__ __forceinline__ void dc_thread_sums(const uint2 *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
                                                uint32_t &y, uint32_t &cb, uint32_t &cr)
 {
     y = cb = cr = 0;
     for (uint32_t mc = m0; mc < m1; mc++) {
-        const int16_t *q = d + (size_t)mc * nb;
-        for (uint32_t k = 0; k < nby; k++) y += (uint32_t)(int)q[k];
-        cb += (uint32_t)(int)q[nby];
-        cr += (uint32_t)(int)q[nby + 1];
+        const uint2 *q = d + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) y += q[k].y;
+        cb += q[nby].y;
+        cr += q[nby + 1].y;
     }
 }
 
@@ -232,7 +198,7 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
     const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     uint32_t y, cb, cr, ty, tcb, tcr;
-    dc_thread_sums(P.dcd + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
+    dc_thread_sums(P.blk + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
     block_excl_scan(y, s_w, &ty);
     block_excl_scan(cb, s_w, &tcb);
     block_excl_scan(cr, s_w, &tcr);
@@ -264,24 +230,22 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     block_excl_scan(pcb, s_w, &bcb);
     block_excl_scan(pcr, s_w, &bcr);
     const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
-    const int16_t *d = P.dcd + im.blk_off;
-    int16_t *o = P.dca + im.blk_off;
+    uint2 *d = P.blk + im.blk_off;
     uint32_t y, cb, cr;
     dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
     y = by + block_excl_scan(y, s_w, &t);
     cb = bcb + block_excl_scan(cb, s_w, &t);
     cr = bcr + block_excl_scan(cr, s_w, &t);
     for (uint32_t mc = m0; mc < m1; mc++) {
-        const int16_t *q = d + (size_t)mc * nb;
-        int16_t *w = o + (size_t)mc * nb;
+        uint2 *q = d + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) {
-            y += (uint32_t)(int)q[k];
-            w[k] = (int16_t)y;
+            y += q[k].y;
+            q[k].y = (uint32_t)(int)(int16_t)y; // int16 wrap of the predictor (loadjpg.cpp:664-665)
         }
-        cb += (uint32_t)(int)q[nby];
-        w[nby] = (int16_t)cb;
-        cr += (uint32_t)(int)q[nby + 1];
-        w[nby + 1] = (int16_t)cr;
+        cb += q[nby].y;
+        q[nby].y = (uint32_t)(int)(int16_t)cb;
+        cr += q[nby + 1].y;
+        q[nby + 1].y = (uint32_t)(int)(int16_t)cr;
     }
 }
 
@@ -297,14 +261,6 @@ int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s)
     hipLaunchKernelGGL(k_unstuff_count, dim3(nchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_unstuff_write, dim3(nchunks), dim3(256), 0, s, P);
-    HJD_LAUNCH_CHECK();
-    return 0;
-}
-
-int hjd_launch_scan(const HjdParams &P, uint32_t nimg, hipStream_t s)
-{
-    if (!nimg) return 0;
-    hipLaunchKernelGGL(k_scan, dim3(nimg), dim3(1024), 0, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }

@@ -26,6 +26,13 @@
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// bytes of the transposed stream of one image: whole groups of 64 subsequences, each subsequence a row of
+// wps + 2 words (its own words and the first two of the next), plus one group of slack
+static inline size_t hjd_ustream_bytes(uint32_t nsub_cap, uint32_t S)
+{
+    return ((size_t)(nsub_cap + 63) / 64 + 1) * ((S / 32) + 2) * 256;
+}
+
 // Makes the decoder's device current for the duration of a call and puts the caller's device back
 // afterwards: a batch may be driven from a thread whose current device is another one.
 struct DeviceGuard {
@@ -49,6 +56,7 @@ struct hjd_decoder {
     int sync_launches = 3; // one synchronisation launch + two repair launches (the second is empty unless a
                            // repaired chain ran across the border of the first one's waves)
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
+    uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
 };
 
@@ -66,18 +74,18 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t chunk0, nchunk, syncwg0, nsyncwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t boff0, nboff; };
+    struct Range { int i0, i1; uint32_t chunk0, nchunk, syncwg0, nsyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
     hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
     uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
     uint8_t *d_mval = nullptr;
-    size_t raw_bytes = 0, ustream_bytes = 0, nblocks_total = 0, nboff = 0, nrec = 0, out_total = 0;
+    size_t raw_bytes = 0, ustream_bytes = 0, nblk_entries = 0, nrec = 0, out_total = 0;
     uint64_t pixels = 0, alg_bytes = 0, scan_bytes = 0;
     // device
     HjdImage *d_img = nullptr;
@@ -85,10 +93,10 @@ struct hjd_batch {
     HjdTableSet *d_tabs = nullptr;
     uint8_t *d_raw = nullptr, *d_ustream = nullptr, *d_out = nullptr;
     uint32_t *d_chunk_kept = nullptr;
-    HjdSub *d_sub = nullptr;
-    HjdSubStart *d_substart = nullptr;
-    int16_t *d_dcd = nullptr, *d_dca = nullptr;
-    uint32_t *d_rec = nullptr, *d_boff = nullptr;
+    uint4 *d_substate = nullptr;
+    uint32_t *d_subcnt = nullptr;
+    uint2 *d_wgsum = nullptr, *d_blk = nullptr;
+    uint32_t *d_rec = nullptr;
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -225,6 +233,8 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
         const char *ek = getenv("HJD_SYNC_OVERLAP");
         if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) d->sync_overlap = (uint32_t)atoi(ek);
+        const char *ep = getenv("HJD_PHASE_WORDS"); // tuning knob: staging window in 32-bit words (power of two)
+        if (ep && atoi(ep) >= 2 && atoi(ep) <= 64 && (atoi(ep) & (atoi(ep) - 1)) == 0) d->phase_words = (uint32_t)atoi(ep);
         if (opt && opt->sync_overlap != 0) {
             if (opt->sync_overlap < -1 || opt->sync_overlap > 48) {
                 delete d;
@@ -250,12 +260,11 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_ustream);
     (void)hipFree(b->d_out);
     (void)hipFree(b->d_chunk_kept);
-    (void)hipFree(b->d_sub);
-    (void)hipFree(b->d_substart);
+    (void)hipFree(b->d_substate);
+    (void)hipFree(b->d_subcnt);
+    (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
-    (void)hipFree(b->d_boff);
-    (void)hipFree(b->d_dcd);
-    (void)hipFree(b->d_dca);
+    (void)hipFree(b->d_blk);
     (void)hipFree(b->d_dcsum);
     (void)hipFree(b->d_chunk_mark);
     (void)hipFree(b->d_mpos);
@@ -285,9 +294,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     const uint32_t S = d->subseq_bits;
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
-    size_t raw_cur = 0, us_cur = 0, blk_cur = 0, boff_cur = 0, rec_cur = 0, out_cur = 0;
+    size_t raw_cur = 0, us_cur = 0, blk_cur = 0, rec_cur = 0, out_cur = 0;
     uint32_t max_nlut = 1, max_nsec = 0;
-    const uint32_t K = d->sync_overlap, Q = 64 - K; // per wave
+    const uint32_t K = d->sync_overlap, Q = HJD_SYNC_WG - K; // owned subsequences per synchronisation workgroup
 
     for (int i = 0; i < b->n; i++) {
         b->dev_index[i] = -1;
@@ -333,10 +342,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
         b->nsub += im.nsub_cap;
         im.syncwg0 = b->nsyncwg;
-        im.nsyncwg = ((im.nsub_cap + Q - 1) / Q + HJD_SYNC_WG / 64 - 1) / (HJD_SYNC_WG / 64); // whole workgroups of independent waves
+        im.nsyncwg = (im.nsub_cap + Q - 1) / Q;
         b->nsyncwg += im.nsyncwg;
+        im.repwg0 = b->nrepwg;
+        im.nrepwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
+        b->nrepwg += im.nrepwg;
         im.writewg0 = b->nwritewg;
-        im.nwritewg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
+        im.nwritewg = (im.nsub_cap + HJD_WRITE_WG - 1) / HJD_WRITE_WG;
         b->nwritewg += im.nwritewg;
         im.dcchunk0 = b->ndcchunks;
         im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
@@ -367,11 +379,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         im.raw_off = raw_cur;
         raw_cur += align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
         im.ustream_off = us_cur;
-        us_cur += ((size_t)im.nwritewg * (HJD_SYNC_WG / 64) + 2) * ((S / 32) + 2) * 256; // 64-row groups of wps+2 words, whole workgroups + slack for prefetch
+        us_cur += hjd_ustream_bytes(im.nsub_cap, S); // whole 64-row groups of wps+2 words
         im.blk_off = blk_cur;
-        blk_cur += im.nblocks;
-        im.boff_off = boff_cur;
-        boff_cur += (size_t)im.nblocks + 1;
+        blk_cur += (size_t)im.nblocks + 1; // + the entry that closes the last block's record range
         {   // record capacity: one per non-zero AC coefficient (<= 63 per block, and every AC symbol with value
             // bits takes at least 2 bits of scan: a 1-bit code for (run 0, size 1) plus the value bit), plus
             // the rounding of every subsequence's run to a whole burst
@@ -396,8 +406,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     b->nimg = (int)b->img.size();
     b->raw_bytes = raw_cur;
     b->ustream_bytes = us_cur;
-    b->nblocks_total = blk_cur;
-    b->nboff = boff_cur;
+    b->nblk_entries = blk_cur;
     b->nrec = rec_cur;
     b->out_total = out_cur;
     b->state.assign(b->nimg, HjdImageState{});
@@ -420,20 +429,20 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_chunk_mark, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
     HIPCHK(hipMalloc(&b->d_mpos, sizeof(uint32_t) * (b->nmarks + 1)));
     HIPCHK(hipMalloc(&b->d_mval, b->nmarks + 1));
-    HIPCHK(hipMalloc(&b->d_sub, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMalloc(&b->d_substart, sizeof(HjdSubStart) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMalloc(&b->d_substate, sizeof(uint4) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMalloc(&b->d_subcnt, sizeof(uint32_t) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMalloc(&b->d_wgsum, sizeof(uint2) * (b->nwritewg ? b->nwritewg : 1)));
     HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
-    HIPCHK(hipMalloc(&b->d_boff, sizeof(uint32_t) * (boff_cur + 1)));
-    HIPCHK(hipMalloc(&b->d_dcd, sizeof(int16_t) * (blk_cur + 1)));
-    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (blk_cur + 1)));
+    HIPCHK(hipMalloc(&b->d_blk, sizeof(uint2) * (blk_cur + 1)));
     HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
-    HIPCHK(hipMemset(b->d_dcd, 0, sizeof(int16_t) * (blk_cur + 1)));
+    HIPCHK(hipMemset(b->d_blk, 0, sizeof(uint2) * (blk_cur + 1)));
     HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(b->d_ustream, 0, us_cur));
     HIPCHK(hipMemset(b->d_st, 0, sizeof(HjdImageState) * b->nimg));
-    HIPCHK(hipMemset(b->d_sub, 0, sizeof(HjdSub) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMemset(b->d_substate, 0, sizeof(uint4) * (b->nsub ? b->nsub : 1)));
+    HIPCHK(hipMemset(b->d_subcnt, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1)));
 
     HjdParams &P = b->P;
     P.img = b->d_img;
@@ -445,17 +454,16 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.chunk_mark = b->d_chunk_mark;
     P.mpos = b->d_mpos;
     P.mval = b->d_mval;
-    P.sub = b->d_sub;
-    P.substart = b->d_substart;
+    P.substate = b->d_substate;
+    P.subcnt = b->d_subcnt;
+    P.wgsum = b->d_wgsum;
     P.rec = b->d_rec;
-    P.boff = b->d_boff;
-    P.dcd = b->d_dcd;
-    P.dca = b->d_dca;
+    P.blk = b->d_blk;
     P.dcsum = b->d_dcsum;
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
-    P.off_chunk = P.off_syncwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
+    P.off_chunk = P.off_syncwg = P.off_repwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
     {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
         int ns = d->streams;
         if (ns > b->nimg) ns = b->nimg;
@@ -478,11 +486,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
             const HjdImage &a = b->img[i0], &z = b->img[i1 - 1];
             r.chunk0 = a.chunk0;       r.nchunk = z.chunk0 + z.nchunks - a.chunk0;
             r.syncwg0 = a.syncwg0;     r.nsyncwg = z.syncwg0 + z.nsyncwg - a.syncwg0;
+            r.repwg0 = a.repwg0;       r.nrepwg = z.repwg0 + z.nrepwg - a.repwg0;
             r.writewg0 = a.writewg0;   r.nwritewg = z.writewg0 + z.nwritewg - a.writewg0;
             r.dc0 = a.dcchunk0;        r.ndc = z.dcchunk0 + z.ndcchunk - a.dcchunk0;
             r.group0 = a.group0;       r.ngroup = z.group0 + z.ngroups - a.group0;
-            r.boff0 = (size_t)a.boff_off;
-            r.nboff = (size_t)(z.boff_off + z.nblocks + 1 - a.boff_off);
+            r.blk0 = (size_t)a.blk_off;
+            r.nblk = (size_t)(z.blk_off + z.nblocks + 1 - a.blk_off);
             b->ranges.push_back(r);
             i0 = i1;
         }
@@ -498,11 +507,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.log2_words = 0;
     while ((32u << P.log2_words) < S) P.log2_words++;
     P.sync_overlap = K;
-    {   // dynamic LDS of the entropy kernels: transposed stream rows, then primary and secondary tables
-        P.lds_lut_word = 0;
-        P.lds_sec_word = P.lds_lut_word + max_nlut * HJD_LUT_SIZE / 2;
-        P.lds_stream_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes = (P.lds_stream_word + (HJD_SYNC_WG / 64) * ((S / 32) + 2) * 64) * 4;
+    {   // dynamic LDS of the entropy kernels: primary and secondary tables, per-workgroup state, then one
+        // staging window of phase_words + 2 words per lane
+        uint32_t wpp = d->phase_words;
+        if (wpp > S / 32) wpp = S / 32;
+        P.phase_words = wpp;
+        P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
+        P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
+        P.lds_bytes_sync = (P.lds_state_word + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_write = (P.lds_state_word + 32 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
     }
     return HJD_OK;
 }
@@ -549,6 +562,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     HjdParams P = b->P;
     P.off_chunk = r.chunk0;
     P.off_syncwg = r.syncwg0;
+    P.off_repwg = r.repwg0;
     P.off_writewg = r.writewg0;
     P.off_img = (uint32_t)r.i0;
     P.off_dcchunk = r.dc0;
@@ -575,15 +589,15 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_repair"))) return rc;
         for (int l = 1; l < b->dec->sync_launches; l++)
-            if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+            if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
     } else {
-        if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
-        if (hjd_launch_sync(P, r.nwritewg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
     }
     if ((rc = mark("scan"))) return rc;
-    if (hjd_launch_scan(P, nimg, s)) return HJD_ERR_INTERNAL;
-    if ((rc = mark("boff_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
-    HIPCHK(hipMemsetAsync(b->d_boff + r.boff0, 0, sizeof(uint32_t) * r.nboff, s));
+    if (hjd_launch_scan(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
+    if ((rc = mark("blk_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
+    HIPCHK(hipMemsetAsync(b->d_blk + r.blk0, 0, sizeof(uint2) * r.nblk, s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
@@ -612,10 +626,11 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.i1 = b->nimg;
         all.nchunk = b->nchunks;
         all.nsyncwg = b->nsyncwg;
+        all.nrepwg = b->nrepwg;
         all.nwritewg = b->nwritewg;
         all.ndc = b->ndcchunks;
         all.ngroup = b->ngroups;
-        all.nboff = b->nboff;
+        all.nblk = b->nblk_entries;
         return range_enqueue(b, all, s, from_resync, nstage, names, evs);
     }
     HIPCHK(hipEventRecord(b->fork_ev, s));
@@ -734,9 +749,9 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
                 overall = HJD_ERR_INTERNAL;
                 break;
             }
-            // everything from k_repair onwards runs again and raises its flags again; what k_unstuff_write
-            // found (a non-RSTn marker between intervals: DIRTY) is not recomputed and must survive
-            for (auto &st : b->state) st.flags &= HJD_FLAG_DIRTY;
+            // everything from k_repair onwards runs again and raises its flags again (the ones a k_write pass
+            // over stale states raised mean nothing); what k_unstuff_write found is not recomputed and must survive
+            for (auto &st : b->state) st.flags &= HJD_FLAG_BAD_MARKER;
             b->resyncs++;
             // keep ustream_len, nmarkers
             std::vector<HjdImageState> tmp = b->state;
@@ -752,7 +767,7 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
         if (st == HJD_OK && di >= 0) {
             const uint32_t f = b->state[di].flags;
             if (f & HJD_FLAG_NOT_CONVERGED) st = HJD_ERR_INTERNAL;
-            else if (f & HJD_FLAG_DIRTY) st = HJD_ERR_DIRTY_RESTART;
+            else if (f & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) st = HJD_ERR_DIRTY_RESTART;
             else if (f & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN | HJD_FLAG_SHORT)) st = HJD_ERR_CORRUPT;
         }
         if (status) status[i] = st;
@@ -798,15 +813,14 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     DeviceGuard guard(b->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     // test hook: rebuild the dense DCT[] rows from the device's sparse form (records + offsets + predicted DC)
-    std::vector<uint32_t> boff(im.nblocks + 1), rec(im.rec_cap);
-    std::vector<int16_t> dc(im.nblocks);
-    HIPCHK(hipMemcpy(boff.data(), b->d_boff + im.boff_off, boff.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint2> blk(im.nblocks + 1);
+    std::vector<uint32_t> rec(im.rec_cap);
+    HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint2), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rec.data(), b->d_rec + im.rec_off, rec.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(dc.data(), b->d_dca + im.blk_off, dc.size() * 2, hipMemcpyDeviceToHost));
     memset(dst, 0, ne * 2);
     for (uint32_t k = 0; k < im.nblocks; k++) {
-        dst[(size_t)k * 64] = dc[k];
-        for (uint32_t t = boff[k]; t < boff[k + 1] && t < im.rec_cap; t++)
+        dst[(size_t)k * 64] = (int16_t)blk[k].y;
+        for (uint32_t t = blk[k].x; t < blk[k + 1].x && t < im.rec_cap; t++)
             if (rec[t] != HJD_REC_PAD) dst[(size_t)k * 64 + ((rec[t] >> 16) & 63)] = (int16_t)(rec[t] & 0xFFFF);
     }
     return HJD_OK;

@@ -106,6 +106,27 @@ def test_decode_hw_validates_caller_filled_tables(hjd, golden):
     assert call(variant(lambda j: None), w=70000) == hjd.HJD_ERR_UNSUPPORTED
 
 
+ROUND2 = ("syn_250x187_420_q85_3dqt.jpg", "syn_250x187_422_q85_3dqt_6huff.jpg", "syn_96x64_444_q60_3dqt_6perm.jpg",
+          "ext_64x64_420_int16wrap.jpg", "ext_64x48_444_dense_ones.jpg")
+
+
+def test_round2_fixtures_are_what_they_claim(hjd, golden):
+    """The fixtures that exist to exercise Cb-uses-Cr's-quantiser (loadjpg.cpp:984) and six-table Huffman
+    configurations really have Cb tq != Cr tq with different table contents, and three table selectors."""
+    d, man = golden
+    for name in ROUND2:
+        data = open(os.path.join(d, name), "rb").read()
+        st, jd = hjd.parse_header(data)
+        assert st == 0
+        assert bytes(jd.qtable[2]) != bytes(jd.qtable[3]), name
+        if "6huff" in name or "6perm" in name or name.startswith("ext_"):
+            assert sorted(jd.dc_table_index[1:4]) == [0, 1, 2] and sorted(jd.ac_table_index[1:4]) == [0, 1, 2], name
+            specs = [bytes(jd.htdc[k].bits) + bytes(jd.htdc[k].vals) for k in range(3)] + \
+                    [bytes(jd.htac[k].bits) + bytes(jd.htac[k].vals) for k in range(3)]
+            if not name.startswith("ext_"):  # the crafted coefficient sets give every component the same statistics
+                assert len(set(specs)) >= 5, name  # six payloads (two DC tables may coincide on tiny inputs)
+
+
 def test_sizes(hjd):
     L = hjd.lib()
     assert L.hjd_bmp_bytes(512, 512) == 786486

@@ -60,23 +60,7 @@ def test_lenna_is_the_reference_bmp(hjd, dec, golden, tmp_path):
 
 
 ROUND2 = ("syn_250x187_420_q85_3dqt.jpg", "syn_250x187_422_q85_3dqt_6huff.jpg", "syn_96x64_444_q60_3dqt_6perm.jpg",
-          "ext_64x64_420_int16wrap.jpg", "ext_64x48_444_dense_ones.jpg")
-
-
-def test_round2_fixtures_are_what_they_claim(hjd, golden):
-    """The fixtures that exist to exercise Cb-uses-Cr's-quantiser (loadjpg.cpp:984) and six-table Huffman
-    configurations really have Cb tq != Cr tq with different table contents, and three table selectors."""
-    d, man = golden
-    for name in ROUND2:
-        data = open(os.path.join(d, name), "rb").read()
-        st, jd = hjd.parse_header(data)
-        assert st == 0
-        assert bytes(jd.qtable[2]) != bytes(jd.qtable[3]), name
-        if "6" in name or name.startswith("ext_"):
-            assert sorted(jd.dc_table_index[1:4]) == [0, 1, 2] and sorted(jd.ac_table_index[1:4]) == [0, 1, 2], name
-            specs = [bytes(jd.htdc[k].bits) + bytes(jd.htdc[k].vals) for k in range(3)] + \
-                    [bytes(jd.htac[k].bits) + bytes(jd.htac[k].vals) for k in range(3)]
-            assert len(set(specs)) >= 5, name  # six payloads (two DC tables may coincide on tiny inputs)
+          "ext_64x64_420_int16wrap.jpg", "ext_64x48_444_dense_ones.jpg")  # what they exercise: tests/test_cabi_cpu.py
 
 
 def test_coefficients_match_oracle(hjd, dec, golden):
