@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
     L.hjd_batch_resync_count.restype = ctypes.c_int
     L.hjd_batch_resync_count.argtypes = [vp]
     L.hjd_decode_batch_host.restype = ctypes.c_int
+    L.hjd_test_color_table.restype = ctypes.c_int
+    L.hjd_test_color_table.argtypes = [vp, vp, sz]
     L.hjd_bmp_bytes.restype = sz
     L.hjd_bmp_bytes.argtypes = [ctypes.c_uint, ctypes.c_uint]
     L.hjd_rgb_bytes.restype = sz
@@ -157,6 +159,14 @@ class Decoder:
             self.close()
         except Exception:  # interpreter shutdown
             pass
+
+    def color_table(self):
+        """Test hook: (256, 256, 256, 3) uint8 array, [Y, Cb, Cr] -> R, G, B as the decode kernel computes them."""
+        buf = np.empty(3 << 24, np.uint8)
+        rc = lib().hjd_test_color_table(self._h, buf.ctypes.data, buf.size)
+        if rc:
+            raise RuntimeError("hjd_test_color_table: %s" % status_string(rc))
+        return buf.reshape(256, 256, 256, 3)
 
     def prepare(self, jpgs, out_format=OUT_RGB):
         return Batch(self, jpgs, out_format)

@@ -10,12 +10,16 @@
 //   subcnt   : per subsequence, blocks completed inside (low 16 bits) | AC records produced inside (high 16)
 //   wgsum    : per final-pass workgroup (HJD_WRITE_WG subsequences): totals of blocks and of records
 //              (each subsequence's records rounded up to HJD_REC_RUN)
-//   rec      : AC coefficient records in decode order (u32: value int16 | zig-zag slot << 16 | (block & 127) << 22;
-//              all ones = padding), every subsequence's run rounded up to HJD_REC_RUN records so that it is
-//              written in aligned 16-byte stores
-//   blk      : one uint2 per block: x = index of the block's first record, y = the decoded DC difference
-//              (k_write), replaced in place by the DC value after prediction (k_dcapply); one extra entry
-//              per image closes the last block's record range
+//   rec      : AC coefficient records in decode order (u32: value int16 | slot << 16 | (block & 127) << 22, where
+//              slot = u*8+v is the coefficient's place after DeZigZag + TransformArray (loadjpg.cpp:156-180), u the
+//              horizontal frequency; all ones = padding), every subsequence's run rounded up to HJD_REC_RUN
+//              records so that it is written in aligned 16-byte stores
+//   blk      : one uint4 per block: x = index of the block's first record, y = the decoded DC difference
+//              (k_write), z/w = 64-bit mask of the slots its AC records fill (those decoded in the subsequence that
+//              holds its DC symbol; later ones are flagged in the record); one extra entry per image closes the
+//              last block's record range
+//   dca      : per block, the DC value after prediction (int16), written by k_dcapply
+//   wgmap    : for every kernel's workgroup numbering, workgroup -> image (one load instead of a search)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan
 //   out      : RGB or BMP bytes
@@ -45,7 +49,7 @@
 // 0.2 % longer than 11, i.e. a 64-lane wave takes the second look-up in 12 % of its steps instead of 50 %.
 #define HJD_SEC_BITS (16 - HJD_LUT_BITS)
 #define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
-#define HJD_MAX_SEC 64
+#define HJD_MAX_SEC 512
 struct HjdTableSet {
     uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)
     uint32_t nsec;       // secondary tables in use
@@ -92,8 +96,14 @@ struct HjdImage {
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)
     uint64_t rec_off;       // first record
     uint64_t out_off;       // byte offset into out slab
-    uint8_t qt[3][64];      // dequantisation tables as USED per component (Cb already holds Cr's), zig-zag order
+    uint8_t qt[3][64];      // dequantisation tables as USED per component (Cb already holds Cr's), indexed by SLOT u*8+v
 };
+
+// zig-zag index -> slot u*8+v (u = horizontal frequency): DeZigZag (natural index v*8+u, table loadjpg.cpp:56-66)
+// followed by TransformArray (loadjpg.cpp:167-180)
+#define HJD_ZZ_TO_SLOT                                                                                                   \
+    {0,  8,  1,  2,  9,  16, 24, 17, 10, 3,  4,  11, 18, 25, 32, 40, 33, 26, 19, 12, 5,  6,  13, 20, 27, 34, 41, 48, 56, 49, 42, 35, \
+     28, 21, 14, 7,  15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63}
 
 // per image, written by the kernels
 struct HjdImageState {
@@ -117,4 +127,5 @@ struct HjdImageState {
 // synchronisation record of one subsequence (substate[]): x = end state bit position (>= end of the
 // subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
+#define HJD_REC_ORPHAN (1u << 29) // the record's block began in an earlier subsequence: its slot is not in the block's mask
 #define HJD_REC_RUN 4 // records per aligned 16-byte store: every subsequence's run is padded to a multiple

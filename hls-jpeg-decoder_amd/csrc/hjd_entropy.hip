@@ -37,6 +37,8 @@
 #include "hjd_kernels.h"
 #include "hjd_kutil.h"
 
+__constant__ uint8_t c_zz_to_slot[64] = HJD_ZZ_TO_SLOT;
+
 struct EntropyLds {
     const uint16_t *lut; // [nlut][HJD_LUT_SIZE]
     const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
@@ -121,17 +123,33 @@ struct WriteCtx {
     uint32_t r0, r1, r2, r3;
     uint32_t *rec;
     uint32_t rec_cap;
-    uint2 *blk;
+    uint4 *blk;
     uint32_t nblocks;
+    const uint8_t *slot_of; // LDS: zig-zag index -> slot u*8+v
+    uint32_t mlo, mhi;      // slots filled by the records of the block in progress (this subsequence's part of it)
+    uint32_t bfirst;        // first record of the block in progress, or ~0 when the block began in an earlier subsequence
+    uint32_t bdc;
 };
+
+// The entry of block b once its last symbol is decoded (or, from the caller, when the subsequence ends inside
+// it): written by the lane that decoded the block's DC symbol (bfirst != ~0), one 16-byte store.
+__device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
+{
+    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint4(W.bfirst, W.bdc, W.mlo, W.mhi);
+    W.bfirst = 0xFFFFFFFFu;
+    W.mlo = W.mhi = 0u;
+}
 
 // Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
 //   WRITE = false: nblk counts blocks completed, nrec the AC records they hold      (synchronisation)
 //   WRITE = true : nblk is the absolute block index, nrec the index of the next record.  Every non-zero
-//                  AC coefficient becomes one record (value | zig-zag slot << 16 | block << 22: the DCT[]
-//                  array of loadjpg.cpp:499-863 in sparse form); blk[b] = (first record of block b, DC
-//                  DIFFERENCE) — DC prediction (loadjpg.cpp:619-667) is a prefix sum done by
-//                  k_dcsum/k_dcapply
+//                  AC coefficient becomes one record (value | slot << 16 | block << 22: the DCT[] array of
+//                  loadjpg.cpp:499-863 in sparse form, already at its place after DeZigZag/TransformArray);
+//                  blk[b] = (first record of block b, DC DIFFERENCE, mask of the slots filled) — DC
+//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcsum/k_dcapply.  The entry
+//                  is written, once and whole, by the lane that decodes the block's DC symbol.  Records of
+//                  a block that began in an earlier subsequence (about one block in 18 straddles) are
+//                  marked HJD_REC_ORPHAN instead: the IDCT kernel adds their slots to the mask itself.
 // `rowp` points at the staged window of the lane's row, `row_bit0` is the absolute bit position of the
 // window's first bit.  tabY/tabCb/tabCr: byte offsets of the component's (DC | AC << 16) primary tables.
 template <bool WRITE, bool RESTART>
@@ -172,15 +190,21 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             const uint32_t vb = ((win << len) >> 1) >> (31u - s);
             const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
             if (isdc) {
-                W.blk[nblk] = make_uint2(nrec, (uint32_t)(int)(int16_t)val);
+                W.bfirst = nrec;
+                W.bdc = (uint32_t)(int)(int16_t)val;
                 // the reference looks for a marker again between the DC code and its extra bits
                 if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
-                uint32_t w = ((uint32_t)val & 0xFFFFu) | (zw << 16) | ((nblk & 127u) << 22);
+                const uint32_t slot = W.slot_of[zw & 63u];
+                uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | ((nblk & 127u) << 22) |
+                             (W.bfirst == 0xFFFFFFFFu ? HJD_REC_ORPHAN : 0u);
                 if (zw > 63u) {
                     flags |= HJD_FLAG_OVERRUN;
                     w = HJD_REC_PAD;
+                } else {
+                    W.mlo |= slot < 32u ? 1u << slot : 0u;
+                    W.mhi |= slot < 32u ? 0u : 1u << (slot - 32u);
                 }
                 W.r0 = W.r1;
                 W.r1 = W.r2;
@@ -200,8 +224,9 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         const bool blk_end = z >= 64u;
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
+            if (WRITE) write_block_entry(W, nblk);
             nblk++;
-            if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint2(nrec, 0u); // end of the last block's records
+            if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
             m = (m + 1u == nb) ? 0u : m + 1u;
             pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
             tb = pair & 0xFFFFu;
@@ -298,8 +323,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
-    const int ii = MODE == 0 ? find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.syncwg0; })
-                             : find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.repwg0; });
+    const int ii = (int)(MODE == 0 ? P.map_syncwg[bid] : P.map_repwg[bid]);
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
     const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_scan(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
     const uint32_t bid = blockIdx.x + P.off_writewg;
-    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
+    const int ii = (int)P.map_writewg[bid];
     const HjdImage &im = P.img[ii];
     const uint32_t S = P.subseq_bits;
     const uint32_t nsub = (P.st[ii].ustream_len * 8u + S - 1) / S;
@@ -475,14 +499,15 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + P.off_writewg;
-    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.writewg0; });
+    const int ii = (int)P.map_writewg[bid];
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - im.writewg0;
 
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
     uint32_t *s_w = s_dyn + P.lds_state_word;
-    uint32_t *s_rows = s_w + 32;
+    uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
+    uint32_t *s_rows = s_w + 48;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits;
@@ -490,6 +515,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     const uint32_t nsub = (total_bits + S - 1) / S;
     if (wg * HJD_WRITE_WG >= nsub) return; // capacity-based grid: nothing in this workgroup
     load_tables(ts, s_lut, s_sec);
+    if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
 
     const uint32_t i = wg * HJD_WRITE_WG + tid;
     const bool valid = i < nsub;
@@ -544,9 +570,11 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     __syncthreads(); // tables are in LDS
 
     uint32_t z = zm & 0xFFu, m = zm >> 8;
-    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks};
+    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks,
+                  s_slot, 0u, 0u, 0xFFFFFFFFu, 0u};
     const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
     decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0);
+    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the subsequence ends inside a block
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
         for (uint32_t q = k; q < HJD_REC_RUN; q++) {

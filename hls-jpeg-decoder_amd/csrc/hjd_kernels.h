@@ -19,7 +19,11 @@ struct HjdParams {
     uint32_t *subcnt;          // per subsequence: blocks | records << 16
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
-    uint2 *blk;                // per block: first record index, DC (difference, then value)
+    uint4 *blk;                // per block: first record index, DC difference, slot mask lo, hi
+    int16_t *dca;              // per block: DC value after prediction
+    // workgroup -> image for every kernel's workgroup numbering (global numbers, like the off_* below)
+    const uint32_t *map_chunk, *map_syncwg, *map_repwg, *map_writewg, *map_dcchunk;
+    const uint2 *map_group;    // IDCT/colour workgroup -> (image, absolute index of its first block in blk)
     uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences
     uint32_t ndcchunks;
     uint8_t *out;              // RGB / BMP bytes
@@ -43,3 +47,4 @@ int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s);
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);
+int hjd_launch_color_table(uint8_t *d_out, hipStream_t s); // test hook: 3 << 24 bytes

@@ -2,23 +2,25 @@
 // output layout.
 //   k_idct_color   DecodeSingleBlock + YCrCB_to_RGB24_Block8x8 (+ WriteBMP24 layout)
 //                  (loadjpg.cpp:184-228, :867-932; openjpg.cpp:504-570)
+//   k_color_table  test hook: the colour stage alone over all 2^24 (Y, Cb, Cr) triples
 //
 // Compile with -ffp-contract=off: the reference's IDCT and colour arithmetic are fp32 with
 // one rounding per operation; an FMA would change output bytes.
+//
+// One workgroup = up to 16 MCUs of one MCU row.  What bounds it on MI355X is not HBM but how long a
+// workgroup lives: round 1's version spent 41 k cycles per workgroup, most of them on nine dependent
+// global round trips (image search, image fields, offsets, records) and eight barriers, for 6 k cycles of
+// own instruction issue.  This version: workgroup -> (image, first block) is one table load, the block
+// entries and the image fields are fetched together, records are scattered by a flat, fully coalesced
+// pass (each record carries its block and its slot), the slot masks come ready from k_write, blocks are
+// dealt to the 4-lane teams component-major (64 luma blocks, then the chroma blocks: similar loop
+// lengths without a sort), and three barriers remain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "hjd_device.h"
 #include "hjd_kernels.h"
 #include "hjd_kutil.h"
-
-// ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
-
-// natural index -> zig-zag index (loadjpg.cpp:56-66)
-__constant__ uint8_t c_zz[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42,
-                                 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
-                                 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
-                                 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 // COS[x][u] = cosf(fl((2x+1)*u*3.14f)/16) exactly as the reference's x86-64/glibc-2.35 build
 // evaluates it (loadjpg.cpp:108,120).  A table, never recomputed: entry [6][7]
@@ -35,38 +37,72 @@ __constant__ float c_cos[64] = {
 
 #define MAXGB (HJD_GROUP_MCUS * 6) // blocks per workgroup
 
-__device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+// ---- colour ------------------------------------------------------------------------------------
+// ConvertYCrCbtoRGB as called at loadjpg.cpp:918 (:867-880): R = (int)(Y + 1.402 (Cr-128)),
+// G = (int)((Y - 0.34414 (Cb-128)) - 0.71414 (Cr-128)), B = (int)(Y + 1.772 (Cb-128)), one fp32
+// rounding per operation, then Clamp (loadjpg.cpp:83-91).  (int) truncates toward zero and Clamp
+// saturates to 0..255; v_trunc_f32 followed by v_cvt_pk_u8_f32 (float -> u8 with saturation, written
+// into a chosen byte of a dword) gives the same byte for every finite input: truncation first makes
+// the value integral, so the conversion's own rounding never acts, negative values saturate to 0
+// like Clamp((int)x) does.  Checked exhaustively over all 2^24 inputs by k_color_table.
 
-// ConvertYCrCbtoRGB as called at loadjpg.cpp:918 (:867-880), one rounding per operation
-__device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, uint32_t &r, uint32_t &g, uint32_t &b)
+struct ChromaTerms {
+    float a, b, c, d; // 1.402 cr', 0.34414 cb', 0.71414 cr', 1.772 cb'   (x' = x - 128)
+};
+
+__device__ __forceinline__ ChromaTerms chroma_terms(uint32_t cb, uint32_t cr)
 {
-    const float fy = (float)y, fcb = (float)(cb - 128), fcr = (float)(cr - 128);
-    const float red = fy + 1.402f * fcr;
-    const float green = (fy - 0.34414f * fcb) - 0.71414f * fcr;
-    const float blue = fy + 1.772f * fcb;
-    r = clamp255((int)red);
-    g = clamp255((int)green);
-    b = clamp255((int)blue);
+    const float fcb = (float)cb - 128.0f, fcr = (float)cr - 128.0f; // == (float)(c - 128) exactly
+    ChromaTerms t;
+    t.a = 1.402f * fcr;
+    t.b = 0.34414f * fcb;
+    t.c = 0.71414f * fcr;
+    t.d = 1.772f * fcb;
+    return t;
 }
+
+// byte `sel` of `acc` <- clamp((int)x, 0, 255)
+__device__ __forceinline__ uint32_t put_u8(float x, uint32_t sel, uint32_t acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(x), sel, acc);
+}
+
+// Four pixels -> the 12 bytes c0,g,c2 x 4 (c0 = R and c2 = B for the m_rgb layout, swapped for BMP).
+// y4 = four luma bytes; t0..t3 = chroma terms of the four pixels (4:2:x callers pass each pair twice).
+__device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const ChromaTerms &t1, const ChromaTerms &t2,
+                                      const ChromaTerms &t3, bool bgr, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+    const float y0 = (float)(y4 & 0xFF), y1 = (float)((y4 >> 8) & 0xFF), y2 = (float)((y4 >> 16) & 0xFF), y3 = (float)(y4 >> 24);
+    const float r0 = y0 + t0.a, g0 = (y0 - t0.b) - t0.c, b0 = y0 + t0.d;
+    const float r1 = y1 + t1.a, g1 = (y1 - t1.b) - t1.c, b1 = y1 + t1.d;
+    const float r2 = y2 + t2.a, g2 = (y2 - t2.b) - t2.c, b2 = y2 + t2.d;
+    const float r3 = y3 + t3.a, g3 = (y3 - t3.b) - t3.c, b3 = y3 + t3.d;
+    const float f0 = bgr ? b0 : r0, l0 = bgr ? r0 : b0;
+    const float f1 = bgr ? b1 : r1, l1 = bgr ? r1 : b1;
+    const float f2 = bgr ? b2 : r2, l2 = bgr ? r2 : b2;
+    const float f3 = bgr ? b3 : r3, l3 = bgr ? r3 : b3;
+    d0 = put_u8(f1, 3, put_u8(l0, 2, put_u8(g0, 1, put_u8(f0, 0, 0u))));
+    d1 = put_u8(g2, 3, put_u8(f2, 2, put_u8(l1, 1, put_u8(g1, 0, 0u))));
+    d2 = put_u8(l3, 3, put_u8(g3, 2, put_u8(f3, 1, put_u8(l2, 0, 0u))));
+}
+
+// ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
 
 __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
 {
-    __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index u*8+v (u = horizontal frequency); +2 pad: bank spread
-    __shared__ uint64_t s_mask[MAXGB];    // bit u*8+v set where the coefficient is non-zero
+    __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index = slot u*8+v (u = horizontal frequency); +2 pad: bank spread
+    __shared__ uint32_t s_mask[MAXGB][2]; // bit = slot holds a coefficient (lo: slots 0-31, hi: 32-63)
+    __shared__ uint8_t s_comp[MAXGB + 32]; // component (0 Y, 1 Cb, 2 Cr) of every block of the group
     __shared__ __attribute__((aligned(8))) uint8_t s_pix[MAXGB][72]; // decoded 8x8 tiles, row-major; +8 pad: bank spread
-    __shared__ __attribute__((aligned(16))) float s_cosT[64]; // [u][x] = COS[x][u]
-    __shared__ __attribute__((aligned(16))) float s_cos[64];  // [v][y] = COS[y][v]  (same matrix, named for its use)
-    __shared__ uint8_t s_qt[3][64];
-    __shared__ uint8_t s_pos[64];
-    __shared__ float s_kk[64];            // C(u)*C(v) by index u*8+v
-    __shared__ uint8_t s_order[MAXGB];
-    __shared__ uint32_t s_hist[66];
-    __shared__ uint32_t s_boff[MAXGB + 1];
-    __shared__ uint8_t s_comp[MAXGB];     // component (0 Y, 1 Cb, 2 Cr) of every block of the group
+    __shared__ __attribute__((aligned(16))) float s_cos[64]; // [u][x] = COS[x][u]; read as [v][y] = COS[y][v] too
+    __shared__ float s_kk[64];            // C(u)*C(v) by slot
+    __shared__ __attribute__((aligned(4))) uint8_t s_qt[3][64]; // by slot
+    __shared__ uint32_t s_range[2];       // records of the group: [first, end)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t bid = blockIdx.x + P.off_group;
-    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &m) { return m.group0; });
+    const uint2 gm = P.map_group[bid];
+    const int ii = (int)gm.x;
     const HjdImage &im = P.img[ii];
     const uint32_t lg = bid - im.group0;
     const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;
@@ -74,123 +110,91 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     const uint32_t K = min((uint32_t)HJD_GROUP_MCUS, im.mcux - mcu_first);
     const uint32_t nb = im.nb, nby = im.nby, hf = im.hf, vf = im.vf;
     const uint32_t KB = K * nb;
-    const uint32_t b0 = (mrow * im.mcux + mcu_first) * nb;
+    const uint32_t lnby = nby >> 1; // log2 for 1, 2, 4
+    const uint32_t nluma = K << lnby;
 
+    // block entries (first record, DC difference, slot mask) and predicted DC — independent of the image fields
+    uint4 be = make_uint4(0u, 0u, 0u, 0u);
+    int dc = 0;
+    if (tid <= KB) be = P.blk[gm.y + tid];
+    if (tid < KB) dc = P.dca[gm.y + tid];
     if (tid < 64) {
-        s_cosT[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
         s_cos[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
-    }
-    if (tid < 192) s_qt[tid >> 6][tid & 63] = im.qt[tid >> 6][tid & 63];
-    if (tid < KB) {
-        const uint32_t mm = tid % nb;
-        s_comp[tid] = (uint8_t)(mm < nby ? 0u : mm - nby + 1u);
-    }
-    if (tid < 64) s_pos[c_zz[tid]] = (uint8_t)((tid & 7) * 8 + (tid >> 3)); // zig-zag slot -> u*8+v (natural tid = v*8+u)
-    if (tid < 64) { // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
+        // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
         const uint32_t u = tid >> 3, v = tid & 7;
         s_kk[tid] = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
     }
+    if (tid < 48) reinterpret_cast<uint32_t *>(&s_qt[0][0])[tid] = reinterpret_cast<const uint32_t *>(&im.qt[0][0])[tid];
+    if (tid <= KB) {
+        const uint32_t first = min(be.x, im.rec_cap);
+        if (tid == 0) s_range[0] = first;
+        if (tid == KB) s_range[1] = first;
+    }
+    uint32_t mycomp = 0;
+    if (tid < KB) {
+        const uint32_t mm = tid % nb;
+        mycomp = mm < nby ? 0u : mm - nby + 1u;
+        s_comp[tid] = (uint8_t)mycomp;
+        s_mask[tid][0] = be.z & ~1u;
+        s_mask[tid][1] = be.w;
+    }
     __syncthreads();
+    if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0 (DequantizeBlock, loadjpg.cpp:144-152: int16 wrap)
+        const int16_t nat = (int16_t)(dc * (int)s_qt[mycomp][0]);
+        s_coef[tid][0] = nat;
+        if (nat != 0) atomicOr(&s_mask[tid][0], 1u);
+    }
 
-    // phase 1: DequantizeBlock + DeZigZag + TransformArray (loadjpg.cpp:144-180) on the sparse form.
-    // Non-zero dequantised values are scattered to their (u,v) slot and flagged in the block's LDS
-    // mask.  int16 wrap of the product as the reference's (short)(int) cast.
+    // phase 1: DequantizeBlock on the sparse form.  The group's records are one contiguous run (padding
+    // included); every record names its block (low 7 bits of the block index) and its slot, so the run is
+    // walked flat, 16 bytes per lane, fully coalesced.  int16 wrap of the product as the reference's
+    // (short)(int) cast.
     {
         const uint32_t *rec = P.rec + im.rec_off;
-        const uint2 *binfo = P.blk + im.blk_off + b0; // (first record, predicted DC) per block
-        uint2 bi = make_uint2(0u, 0u);
-        if (tid <= KB) {
-            bi = binfo[tid];
-            s_boff[tid] = min(bi.x, im.rec_cap);
-        }
-        if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0
-            const uint32_t comp = s_comp[tid];
-            const int16_t nat = (int16_t)((int)(int16_t)bi.y * (int)s_qt[comp][0]);
-            s_coef[tid][0] = nat;
-            s_mask[tid] = nat != 0 ? 1ull : 0ull;
-        }
-        __syncthreads();
-        // sixteen threads per block walk its record range [boff[b], boff[b+1]) (contiguous, so the team's
-        // loads coalesce); r1 < r0 after a corrupt stream simply yields no work.  The first record of
-        // every (thread, block) pair is requested before any is used, so that a workgroup pays the global
-        // memory latency once instead of once per pass.
-        constexpr int NPASS = MAXGB / 16;
-        uint32_t w0[NPASS];
+        const uint32_t r0 = s_range[0], r1 = s_range[1];
+        const uint32_t b0 = (uint32_t)(gm.y - im.blk_off);
+        for (uint32_t t = (r0 & ~3u) + tid * 4u; t < r1; t += 1024u) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(rec + t);
+            const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int k = 0; k < NPASS; k++) {
-            const uint32_t blk = (tid >> 4) + 16u * k;
-            w0[k] = HJD_REC_PAD;
-            if (blk < KB) {
-                const uint32_t t = s_boff[blk] + (tid & 15u);
-                if (t < s_boff[blk + 1]) w0[k] = rec[t];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NPASS; k++) {
-            const uint32_t blk = (tid >> 4) + 16u * k;
-            if (blk >= KB) break;
-            const uint32_t r1 = s_boff[blk + 1];
-            const uint32_t comp = s_comp[blk];
-            unsigned long long mk = 0;
-            uint32_t w = w0[k];
-            for (uint32_t t = s_boff[blk] + (tid & 15u); t < r1;) {
-                if (w != HJD_REC_PAD) {
-                    const uint32_t zz = (w >> 16) & 63u;
-                    const int16_t nat = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[comp][zz]);
-                    if (nat != 0) {
-                        const uint32_t pos = s_pos[zz];
-                        s_coef[blk][pos] = nat;
-                        mk |= 1ull << pos;
-                    }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = w4[k];
+                const uint32_t rel = ((w >> 22) - b0) & 127u;
+                if (w != HJD_REC_PAD && t + k >= r0 && t + k < r1 && rel < KB) {
+                    const uint32_t slot = (w >> 16) & 63u;
+                    s_coef[rel][slot] = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[s_comp[rel]][slot]);
+                    if (w & HJD_REC_ORPHAN) atomicOr(&s_mask[rel][slot >> 5], 1u << (slot & 31u)); // its block's entry was written before this record existed
                 }
-                t += 16;
-                if (t < r1) w = rec[t]; // blocks with more than 16 records (rare)
             }
-            if (mk) atomicOr(reinterpret_cast<unsigned long long *>(&s_mask[blk]), mk);
         }
     }
     __syncthreads();
 
-    // Blocks are handed to the 4-lane teams in order of decreasing non-zero count, so that the sixteen
-    // teams of a wave run loops of similar length: counting sort over the 65 possible counts.
-    if (tid < 66) s_hist[tid] = 0;
-    __syncthreads();
-    uint32_t my_cnt = 0, my_slot = 0;
-    if (tid < KB) {
-        my_cnt = (uint32_t)__popcll((unsigned long long)s_mask[tid]);
-        my_slot = atomicAdd(&s_hist[64u - my_cnt], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) { // exclusive prefix over buckets 0..64 (bucket 64 = empty blocks, placed last)
-        const uint32_t h = s_hist[tid];
-        const uint32_t inc = wave_incl_scan(h);
-        s_hist[tid] = inc - h;
-        if (tid == 63) s_hist[64] = inc;
-    }
-    __syncthreads();
-    if (tid < KB) s_order[s_hist[64u - my_cnt] + my_slot] = (uint8_t)tid;
-    __syncthreads();
-
-    // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Thread = (block, two output columns
-    // x0, x0+1), 2 x 8 row accumulators.  Terms are added in the reference's order (u outer, v inner);
-    // zero coefficients add +-0 and are skipped.  term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].
+    // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Team of 4 lanes = one block; lane = two output
+    // columns x0, x0+1 with 2 x 8 row accumulators.  Terms are added in the reference's order (u outer, v
+    // inner = ascending slot); empty slots would add +-0 and are skipped.
+    // term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].  Blocks are dealt component-major: team s < nluma
+    // takes a luma block, the rest the chroma blocks.
     {
         const uint32_t x0 = (tid & 3) * 2;
-        for (uint32_t slot = tid >> 2; slot < KB; slot += 64) {
-            const uint32_t blk = s_order[slot];
+        for (uint32_t s = tid >> 2; s < KB; s += 64) {
+            uint32_t blk;
+            if (s < nluma) blk = (s >> lnby) * nb + (s & (nby - 1u));
+            else blk = ((s - nluma) >> 1) * nb + nby + ((s - nluma) & 1u);
             float acc0[8], acc1[8];
 #pragma unroll
             for (int y = 0; y < 8; y++) acc0[y] = acc1[y] = 0.0f;
-            const uint64_t mk = s_mask[blk];
+            const uint2 mk = *reinterpret_cast<const uint2 *>(&s_mask[blk][0]);
+            const int16_t *cf = &s_coef[blk][0];
 #pragma unroll
             for (int half = 0; half < 2; half++) { // u = 0..3, then u = 4..7: ascending set bits = the term order
-                uint32_t m32 = half ? (uint32_t)(mk >> 32) : (uint32_t)mk;
+                uint32_t m32 = half ? mk.y : mk.x;
                 while (m32) {
                     const uint32_t j = half * 32u + (uint32_t)__ffs((int)m32) - 1u;
                     m32 &= m32 - 1u;
                     const uint32_t u = j >> 3, v = j & 7;
-                    const float t1 = s_kk[j] * (float)s_coef[blk][j];
-                    const float2 cx = *reinterpret_cast<const float2 *>(&s_cosT[u * 8 + x0]);
+                    const float t1 = s_kk[j] * (float)cf[j];
+                    const float2 cx = *reinterpret_cast<const float2 *>(&s_cos[u * 8 + x0]);
                     const float t2a = t1 * cx.x, t2b = t1 * cx.y;
                     const float4 ca = *reinterpret_cast<const float4 *>(&s_cos[v * 8]);
                     const float4 cb = *reinterpret_cast<const float4 *>(&s_cos[v * 8 + 4]);
@@ -205,8 +209,10 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
 #pragma unroll
             for (int y = 0; y < 8; y++) {
                 // (int)(0.25*sum) then short +128 then Clamp (loadjpg.cpp:123,136-137,219)
-                const int16_t ta = (int16_t)(int)(acc0[y] * 0.25f), tb = (int16_t)(int)(acc1[y] * 0.25f);
-                const uint32_t pa = clamp255((int16_t)(ta + 128)), pb = clamp255((int16_t)(tb + 128));
+                // (int16)((int16)t + 128) == (int16)(t + 128): one wrap
+                const int ta = (int)(int16_t)((int)(acc0[y] * 0.25f) + 128);
+                const int tb = (int)(int16_t)((int)(acc1[y] * 0.25f) + 128);
+                const uint32_t pa = (uint32_t)min(max(ta, 0), 255), pb = (uint32_t)min(max(tb, 0), 255);
                 *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)(pa | (pb << 8));
             }
         }
@@ -240,57 +246,35 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             const uint32_t cy = row >> lvf;
             const uint8_t *pcb = &s_pix[k * nb + nby][cy * 8];
             const uint8_t *pcr = &s_pix[k * nb + nby + 1][cy * 8];
-            uint32_t rr[4], gg[4], bb[4];
+            uint32_t d0, d1, d2;
             if (hf == 2) {
                 // 4:2:x — pixels 0,1 and 2,3 share a chroma sample (cx = x/2, loadjpg.cpp:912): the four
                 // chroma products are formed once per sample; every operation is the same fp32 operation
-                // ConvertYCrCbtoRGB performs ((float)(c - 128) == (float)c - 128.0f exactly)
+                // ConvertYCrCbtoRGB performs
                 const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb[xin >> 1]);
                 const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr[xin >> 1]);
-#pragma unroll
-                for (int h2 = 0; h2 < 2; h2++) {
-                    const float fcb = (float)((cb2 >> (8 * h2)) & 0xFF) - 128.0f;
-                    const float fcr = (float)((cr2 >> (8 * h2)) & 0xFF) - 128.0f;
-                    const float pa = 1.402f * fcr, pb = 0.34414f * fcb, pc = 0.71414f * fcr, pd = 1.772f * fcb;
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int j = 2 * h2 + q;
-                        const float fy = (float)((ypix >> (8 * j)) & 0xFF);
-                        rr[j] = clamp255((int)(fy + pa));
-                        gg[j] = clamp255((int)((fy - pb) - pc));
-                        bb[j] = clamp255((int)(fy + pd));
-                    }
-                }
+                const ChromaTerms ta = chroma_terms(cb2 & 0xFF, cr2 & 0xFF), tb = chroma_terms(cb2 >> 8, cr2 >> 8);
+                rgb12(ypix, ta, ta, tb, tb, bmp, d0, d1, d2);
+            } else if (hf == 4) {
+                const ChromaTerms ta = chroma_terms(pcb[xin >> 2], pcr[xin >> 2]);
+                rgb12(ypix, ta, ta, ta, ta, bmp, d0, d1, d2);
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t cx = (xin + j) >> lhf; // loadjpg.cpp:912
-                    ycc_to_rgb((int)((ypix >> (8 * j)) & 0xFF), (int)pcb[cx], (int)pcr[cx], rr[j], gg[j], bb[j]);
-                }
+                const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb[xin]);
+                const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr[xin]);
+                rgb12(ypix, chroma_terms(cb4 & 0xFF, cr4 & 0xFF), chroma_terms((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF),
+                      chroma_terms((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF), chroma_terms(cb4 >> 24, cr4 >> 24), bmp, d0, d1, d2);
             }
             const uint32_t nvalid = min(4u, W - gxp);
             uint8_t *dst;
             if (bmp) dst = out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3;
             else dst = out + (size_t)gy * stride + (size_t)gxp * 3;
-            uint32_t c0[4], c2[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                c0[j] = bmp ? bb[j] : rr[j];
-                c2[j] = bmp ? rr[j] : bb[j];
-            }
             if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
                 struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
-                Px12 v12;
-                v12.a = c0[0] | (gg[0] << 8) | (c2[0] << 16) | (c0[1] << 24);
-                v12.b = gg[1] | (c2[1] << 8) | (c0[2] << 16) | (gg[2] << 24);
-                v12.c = c2[2] | (c0[3] << 8) | (gg[3] << 16) | (c2[3] << 24);
+                Px12 v12 = {d0, d1, d2};
                 *reinterpret_cast<Px12 *>(dst) = v12; // one 12-byte store: a wave writes 768 contiguous bytes
             } else {
-                for (uint32_t j = 0; j < nvalid; j++) {
-                    dst[j * 3 + 0] = (uint8_t)c0[j];
-                    dst[j * 3 + 1] = (uint8_t)gg[j];
-                    dst[j * 3 + 2] = (uint8_t)c2[j];
-                }
+                const uint32_t dd[3] = {d0, d1, d2};
+                for (uint32_t j = 0; j < nvalid * 3; j++) dst[j] = (uint8_t)(dd[j >> 2] >> ((j & 3) * 8));
             }
             if (bmp && gxp + nvalid == W) { // row padding (openjpg.cpp:563-567), written as zeros
                 for (uint32_t q = 3 * W; q < stride; q++) out[54 + (size_t)(H - 1 - gy) * stride + q] = 0;
@@ -314,10 +298,32 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
 }
 
+// Test hook: the colour stage, alone, over every (Y, Cb, Cr) triple.  Output: 3 bytes
+// R,G,B at index (Y << 16 | Cb << 8 | Cr) * 3, produced by the very functions k_idct_color uses.
+__global__ __launch_bounds__(256) void k_color_table(uint8_t *out)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x; // (Y, Cb, quarter of Cr): four triples with consecutive Cr
+    const uint32_t y = t >> 14, cb = (t >> 6) & 0xFF, cr0 = (t & 63u) * 4u;
+    uint32_t d0, d1, d2;
+    rgb12(y * 0x01010101u, chroma_terms(cb, cr0), chroma_terms(cb, cr0 + 1), chroma_terms(cb, cr0 + 2), chroma_terms(cb, cr0 + 3),
+          false, d0, d1, d2);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)((y << 16) | (cb << 8) | cr0) * 3u);
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+}
+
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s)
 {
     if (!ngroups) return 0;
     hipLaunchKernelGGL(k_idct_color, dim3(ngroups), dim3(256), 0, s, P);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int hjd_launch_color_table(uint8_t *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_color_table, dim3((1u << 22) / 256), dim3(256), 0, s, d_out);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

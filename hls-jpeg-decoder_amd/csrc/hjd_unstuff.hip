@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
     __shared__ uint8_t s_edge[512];
     __shared__ uint32_t s_w[17];
     const uint32_t c = blockIdx.x + P.off_chunk;
-    const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
+    const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
     uint4 v;
     uint32_t marks;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
     __shared__ __attribute__((aligned(4))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 8];
     __shared__ uint32_t s_w[17];
     const uint32_t c = blockIdx.x + P.off_chunk;
-    const int ii = find_image(P.img, P.nimg, c, [](const HjdImage &m) { return m.chunk0; });
+    const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
     const uint32_t lc = c - im.chunk0;
     // kept bytes and markers of this image's earlier chunks
@@ -171,17 +171,17 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
 // (loadjpg.cpp:619-667, :1159-1162), int16 wrap (loadjpg.cpp:664-665) = prefix sums mod 2^16 over the
 // blocks of each component in decode order.  Two passes over chunks of HJD_DC_CHUNK MCUs:
 // k_dcsum (per-chunk totals), k_dcapply (totals of the earlier chunks + scan inside the chunk).
-// The differences sit in blk[].y (written by k_write) and are replaced IN PLACE by the predicted values,
-// so that the IDCT kernel reads one 8-byte entry per block (first record, DC).
+// The differences sit in blk[].y (written by k_write); the predicted values go to the compact array dca[]
+// (a thread's 2-byte stores are contiguous: whole sectors leave the wave).
 
 #define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
 
-__device__ __forceinline__ void dc_thread_sums(const uint2 *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+__device__ __forceinline__ void dc_thread_sums(const uint4 *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
                                                uint32_t &y, uint32_t &cb, uint32_t &cr)
 {
     y = cb = cr = 0;
     for (uint32_t mc = m0; mc < m1; mc++) {
-        const uint2 *q = d + (size_t)mc * nb;
+        const uint4 *q = d + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) y += q[k].y;
         cb += q[nby].y;
         cr += q[nby + 1].y;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
     const uint32_t bid = blockIdx.x + P.off_dcchunk;
-    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.dcchunk0; });
+    const int ii = (int)P.map_dcchunk[bid];
     const HjdImage &im = P.img[ii];
     const uint32_t nmcu = im.mcux * im.mcuy;
     const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
 {
     __shared__ uint32_t s_w[17];
     const uint32_t bid = blockIdx.x + P.off_dcchunk;
-    const int ii = find_image(P.img, P.nimg, bid, [](const HjdImage &q) { return q.dcchunk0; });
+    const int ii = (int)P.map_dcchunk[bid];
     const HjdImage &im = P.img[ii];
     const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t nmcu = im.mcux * im.mcuy;
@@ -230,22 +230,24 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     block_excl_scan(pcb, s_w, &bcb);
     block_excl_scan(pcr, s_w, &bcr);
     const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
-    uint2 *d = P.blk + im.blk_off;
+    const uint4 *d = P.blk + im.blk_off;
+    int16_t *o = P.dca + im.blk_off;
     uint32_t y, cb, cr;
     dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
     y = by + block_excl_scan(y, s_w, &t);
     cb = bcb + block_excl_scan(cb, s_w, &t);
     cr = bcr + block_excl_scan(cr, s_w, &t);
     for (uint32_t mc = m0; mc < m1; mc++) {
-        uint2 *q = d + (size_t)mc * nb;
+        const uint4 *q = d + (size_t)mc * nb;
+        int16_t *w = o + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) {
             y += q[k].y;
-            q[k].y = (uint32_t)(int)(int16_t)y; // int16 wrap of the predictor (loadjpg.cpp:664-665)
+            w[k] = (int16_t)y; // int16 wrap of the predictor (loadjpg.cpp:664-665)
         }
         cb += q[nby].y;
-        q[nby].y = (uint32_t)(int)(int16_t)cb;
+        w[nby] = (int16_t)cb;
         cr += q[nby + 1].y;
-        q[nby + 1].y = (uint32_t)(int)(int16_t)cr;
+        w[nby + 1] = (int16_t)cr;
     }
 }
 

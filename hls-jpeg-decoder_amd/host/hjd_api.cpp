@@ -26,6 +26,8 @@
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+static const uint8_t kZzToSlot[64] = HJD_ZZ_TO_SLOT;
+
 // bytes of the transposed stream of one image: whole groups of 64 subsequences, each subsequence a row of
 // wps + 2 words (its own words and the first two of the next), plus one group of slack
 static inline size_t hjd_ustream_bytes(uint32_t nsub_cap, uint32_t S)
@@ -95,8 +97,11 @@ struct hjd_batch {
     uint32_t *d_chunk_kept = nullptr;
     uint4 *d_substate = nullptr;
     uint32_t *d_subcnt = nullptr;
-    uint2 *d_wgsum = nullptr, *d_blk = nullptr;
+    uint2 *d_wgsum = nullptr;
+    uint4 *d_blk = nullptr;
+    int16_t *d_dca = nullptr;
     uint32_t *d_rec = nullptr;
+    uint32_t *d_maps = nullptr; // workgroup -> image tables of all kernels, one allocation
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -265,6 +270,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_blk);
+    (void)hipFree(b->d_dca);
+    (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
     (void)hipFree(b->d_chunk_mark);
     (void)hipFree(b->d_mpos);
@@ -391,10 +398,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         }
         im.rec_off = rec_cur;
         rec_cur += im.rec_cap;
-        // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's
-        memcpy(im.qt[0], j.qtable[1], 64);
-        memcpy(im.qt[1], j.qtable[3], 64);
-        memcpy(im.qt[2], j.qtable[3], 64);
+        // dequantisation tables as the reference USES them: Y -> Y's, Cb -> Cr's (loadjpg.cpp:984), Cr -> Cr's;
+        // stored by slot u*8+v (where DeZigZag + TransformArray put zig-zag entry k, loadjpg.cpp:156-180)
+        for (int k = 0; k < 64; k++) {
+            im.qt[0][kZzToSlot[k]] = j.qtable[1][k];
+            im.qt[1][kZzToSlot[k]] = j.qtable[3][k];
+            im.qt[2][kZzToSlot[k]] = j.qtable[3][k];
+        }
         b->dev_index[i] = (int)b->img.size();
         b->img.push_back(im);
         b->out_bytes.push_back(obytes);
@@ -433,9 +443,48 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     HIPCHK(hipMalloc(&b->d_subcnt, sizeof(uint32_t) * (b->nsub ? b->nsub : 1)));
     HIPCHK(hipMalloc(&b->d_wgsum, sizeof(uint2) * (b->nwritewg ? b->nwritewg : 1)));
     HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
-    HIPCHK(hipMalloc(&b->d_blk, sizeof(uint2) * (blk_cur + 1)));
+    HIPCHK(hipMalloc(&b->d_blk, sizeof(uint4) * (blk_cur + 1)));
+    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
     HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
-    HIPCHK(hipMemset(b->d_blk, 0, sizeof(uint2) * (blk_cur + 1)));
+    HIPCHK(hipMemset(b->d_blk, 0, sizeof(uint4) * (blk_cur + 1)));
+    {   // workgroup -> image for every kernel's workgroup numbering; IDCT groups also get their first block
+        std::vector<uint32_t> maps;
+        size_t off_chunk = 0, off_sync, off_rep, off_write, off_dc, off_group;
+        auto fill = [&](uint32_t HjdImage::*first, uint32_t HjdImage::*count) {
+            const size_t at = maps.size();
+            for (int k = 0; k < b->nimg; k++) {
+                if (maps.size() != at + b->img[k].*first) return (size_t)-1;
+                maps.insert(maps.end(), b->img[k].*count, (uint32_t)k);
+            }
+            return at;
+        };
+        off_chunk = fill(&HjdImage::chunk0, &HjdImage::nchunks);
+        off_sync = fill(&HjdImage::syncwg0, &HjdImage::nsyncwg);
+        off_rep = fill(&HjdImage::repwg0, &HjdImage::nrepwg);
+        off_write = fill(&HjdImage::writewg0, &HjdImage::nwritewg);
+        off_dc = fill(&HjdImage::dcchunk0, &HjdImage::ndcchunk);
+        if (off_chunk == (size_t)-1 || off_sync == (size_t)-1 || off_rep == (size_t)-1 || off_write == (size_t)-1 || off_dc == (size_t)-1)
+            return HJD_ERR_INTERNAL;
+        if (maps.size() & 1) maps.push_back(0); // the uint2 table that follows is 8-byte aligned
+        off_group = maps.size();
+        for (int k = 0; k < b->nimg; k++) {
+            const HjdImage &im = b->img[k];
+            for (uint32_t g = 0; g < im.ngroups; g++) {
+                const uint32_t mrow = g / im.groups_per_row, gx = g % im.groups_per_row;
+                maps.push_back((uint32_t)k);
+                maps.push_back((uint32_t)(im.blk_off + ((size_t)mrow * im.mcux + (size_t)gx * HJD_GROUP_MCUS) * im.nb));
+            }
+        }
+        if (blk_cur >= 0xFFFFFFFFull) return HJD_ERR_UNSUPPORTED;
+        HIPCHK(hipMalloc(&b->d_maps, sizeof(uint32_t) * (maps.size() + 2)));
+        HIPCHK(hipMemcpy(b->d_maps, maps.data(), sizeof(uint32_t) * maps.size(), hipMemcpyHostToDevice));
+        b->P.map_chunk = b->d_maps + off_chunk;
+        b->P.map_syncwg = b->d_maps + off_sync;
+        b->P.map_repwg = b->d_maps + off_rep;
+        b->P.map_writewg = b->d_maps + off_write;
+        b->P.map_dcchunk = b->d_maps + off_dc;
+        b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
+    }
     HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
@@ -459,6 +508,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     P.wgsum = b->d_wgsum;
     P.rec = b->d_rec;
     P.blk = b->d_blk;
+    P.dca = b->d_dca;
     P.dcsum = b->d_dcsum;
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
@@ -515,7 +565,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_bytes_sync = (P.lds_state_word + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
-        P.lds_bytes_write = (P.lds_state_word + 32 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_write = (P.lds_state_word + 48 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
     }
     return HJD_OK;
 }
@@ -597,7 +647,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     if ((rc = mark("scan"))) return rc;
     if (hjd_launch_scan(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("blk_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
-    HIPCHK(hipMemsetAsync(b->d_blk + r.blk0, 0, sizeof(uint2) * r.nblk, s));
+    HIPCHK(hipMemsetAsync(b->d_blk + r.blk0, 0, sizeof(uint4) * r.nblk, s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
@@ -813,17 +863,35 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     DeviceGuard guard(b->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     // test hook: rebuild the dense DCT[] rows from the device's sparse form (records + offsets + predicted DC)
-    std::vector<uint2> blk(im.nblocks + 1);
+    std::vector<uint4> blk(im.nblocks + 1);
     std::vector<uint32_t> rec(im.rec_cap);
-    HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    uint8_t slot_to_zz[64];
+    for (int k = 0; k < 64; k++) slot_to_zz[kZzToSlot[k]] = (uint8_t)k;
+    std::vector<int16_t> dca(im.nblocks);
+    HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dca.data(), b->d_dca + im.blk_off, dca.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rec.data(), b->d_rec + im.rec_off, rec.size() * 4, hipMemcpyDeviceToHost));
     memset(dst, 0, ne * 2);
     for (uint32_t k = 0; k < im.nblocks; k++) {
-        dst[(size_t)k * 64] = (int16_t)blk[k].y;
+        dst[(size_t)k * 64] = dca[k];
         for (uint32_t t = blk[k].x; t < blk[k + 1].x && t < im.rec_cap; t++)
-            if (rec[t] != HJD_REC_PAD) dst[(size_t)k * 64 + ((rec[t] >> 16) & 63)] = (int16_t)(rec[t] & 0xFFFF);
+            if (rec[t] != HJD_REC_PAD) dst[(size_t)k * 64 + slot_to_zz[(rec[t] >> 16) & 63]] = (int16_t)(rec[t] & 0xFFFF);
     }
     return HJD_OK;
+}
+
+extern "C" int hjd_test_color_table(hjd_decoder *d, uint8_t *dst, size_t cap)
+{
+    const size_t n = (size_t)3 << 24;
+    if (!d || !dst || cap < n) return HJD_ERR_ARG;
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
+    uint8_t *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, n));
+    int rc = hjd_launch_color_table(dev, nullptr) ? HJD_ERR_INTERNAL : HJD_OK;
+    if (rc == HJD_OK && hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost) != hipSuccess) rc = HJD_ERR_INTERNAL;
+    (void)hipFree(dev);
+    return rc;
 }
 
 extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)

@@ -178,6 +178,10 @@ size_t hjd_rgb_bytes(unsigned width, unsigned height);
  * oracle in isolation.  coefs: nblocks*64 int16, zig-zag order, DC predictor applied (the
  * DCT[] array after ProcessHuffmanBlock, loadjpg.cpp:499-863). */
 int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_t dst_elems);
+/* The colour stage alone (ConvertYCrCbtoRGB + Clamp, loadjpg.cpp:867-880, :83-91) over all 2^24 inputs, run by
+ * the device functions the decode kernel uses: dst[((Y << 16 | Cb << 8 | Cr) * 3) + {0,1,2}] = R, G, B.
+ * dst_cap >= 3 << 24 bytes (host memory). */
+int hjd_test_color_table(hjd_decoder *d, uint8_t *dst, size_t dst_cap);
 
 #ifdef __cplusplus
 }

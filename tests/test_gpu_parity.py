@@ -370,6 +370,68 @@ def test_internal_streams(hjd, golden, streams):
     d.close()
 
 
+def test_colour_stage_exhaustive(hjd, dec):
+    """ConvertYCrCbtoRGB + Clamp (loadjpg.cpp:867-880, :83-91) over ALL 2^24 (Y, Cb, Cr) triples, computed
+    on the device by the functions the decode kernel uses (hjd_test_color_table), against the oracle's formula.  The
+    numpy restatement used for the bulk comparison is itself pinned to the oracle's C function on 20 000 samples."""
+    import ctypes
+    got = dec.color_table()
+    f = np.float32
+    cb = np.arange(256, dtype=np.int32)[:, None]
+    cr = np.arange(256, dtype=np.int32)[None, :]
+    fcb, fcr = (cb - 128).astype(f), (cr - 128).astype(f)
+    a, b, c, d = f(1.402) * fcr, f(0.34414) * fcb, f(0.71414) * fcr, f(1.772) * fcb
+
+    def expect(y):
+        fy = f(y)
+        r = np.broadcast_to(fy + a, (256, 256))
+        g = (fy - b) - c
+        bl = np.broadcast_to(fy + d, (256, 256))
+        return np.stack([np.clip(v.astype(np.int32), 0, 255).astype(np.uint8) for v in (r, g, bl)], axis=-1)
+
+    o = T.oracle_lib()
+    o.hjo_ycc_to_rgb.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
+    rng = np.random.default_rng(1)
+    px = np.zeros(3, np.uint8)
+    exp_cache = {}
+    for y, u, v in rng.integers(0, 256, (20000, 3)):
+        o.hjo_ycc_to_rgb(int(y), int(u), int(v), px.ctypes.data, px.ctypes.data + 1, px.ctypes.data + 2)
+        if int(y) not in exp_cache:
+            exp_cache[int(y)] = expect(int(y))
+        assert tuple(exp_cache[int(y)][u, v]) == tuple(px), (y, u, v)
+    bad = 0
+    for y in range(256):
+        bad += int((got[y] != (exp_cache.get(y) if y in exp_cache else expect(y))).any(axis=-1).sum())
+    assert bad == 0, "%d of 16777216 triples differ" % bad
+
+
+def test_overflow_stress_blocks_through_the_back_end(hjd, dec):
+    """chosen coefficient blocks -> tiles on the device.  Blocks with magnitudes up to 32767 and
+    quantisers up to 255 (products that wrap int16, sums that saturate Clamp), dense and sparse, fed to the
+    back end by coding exactly those coefficients into a scan (tools/jpeg_enc.c, explicit-coefficient mode)."""
+    rng = np.random.default_rng(8)
+    w, h = 256, 128                      # 4:4:4 -> 512 MCUs x 3 blocks
+    nb = (w // 8) * (h // 8) * 3
+    co = np.zeros((nb, 64), np.int16)
+    for b in range(nb):
+        k = int(rng.integers(0, 64))
+        idx = rng.choice(np.arange(1, 64), min(k, 63), replace=False)
+        scale = [8, 200, 2047, 32767][b % 4]
+        co[b, idx] = rng.integers(-scale, scale + 1, len(idx))
+    co[:, 0] = rng.integers(-30000, 30001, nb)
+    qt = rng.integers(1, 256, (3, 64)).astype(np.uint8)
+    j = T.encode_jpeg_ex(None, 85, 1, 1, 0, True, T.HUFF_SIX_OPTIMISED, qtab=qt, coefs=co, size=(w, h))
+    orc, orgb, ocoef, _, _ = T.oracle_decode(j, want_coefs=True)
+    assert orc == 0 and np.array_equal(ocoef, co)          # the scan really carries the chosen blocks
+    st, outs = dec.decode([j])
+    assert st == [0] and np.array_equal(outs[0], orgb)
+    b = dec.prepare([j])
+    b.run()
+    assert b.finish() == [0]
+    assert np.array_equal(b.download_coefs(0, nb), co)
+    b.close()
+
+
 def test_two_ranks_share_one_batch(hjd, tmp_path):
     """The N > 1 code path on the hardware at hand: two ranks (own processes, gloo on 127.0.0.1, both on device 0)
     decode the two shards shard.partition() gives them of ONE 64-image mixed batch.  Union = every image exactly
