@@ -33,7 +33,7 @@
 #define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
-#define HJD_DC_CHUNK 1024      // MCUs per DC-prediction workgroup
+#define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 
 // Huffman decode tables of one distinct (DC/AC x 3 components) configuration.
 // Primary table: indexed by the next HJD_LUT_BITS bits.  Entry (u16):

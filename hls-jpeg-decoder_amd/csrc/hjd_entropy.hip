@@ -314,6 +314,8 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
 // MODE 1: repair / host re-synchronisation: HJD_SYNC_WG owned subsequences per workgroup, records reloaded,
 //         slot 0 takes its start from the previous workgroup's last record.  Returns at once (before the
 //         tables are even loaded) when every start state already equals its predecessor's end.
+// MODE 2: MODE 1 for the last repair launch, which also leaves the block / record totals of the final-pass
+//         workgroups it covers (k_scan's job when no repair launch is configured).
 
 template <int MODE>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
@@ -324,6 +326,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
     const int ii = (int)(MODE == 0 ? P.map_syncwg[bid] : P.map_repwg[bid]);
+    static_assert(HJD_SYNC_WG == 2 * HJD_WRITE_WG, "a repair workgroup covers exactly two final-pass workgroups");
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
     const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
@@ -451,6 +454,27 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         __syncthreads();
     }
 
+    if (MODE == 2) { // totals of the two final-pass workgroups whose subsequences this workgroup holds
+        const uint32_t c = valid ? s_cnt[tid] : 0u;
+        const uint32_t tb = wave_incl_scan(c & 0xFFFFu);
+        const uint32_t tr = wave_incl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u)); // every run is stored in whole bursts
+        __syncthreads(); // everyone is done with s_lp / s_lzm
+        if (lane == 63) {
+            s_lp[wv] = tb;
+            s_lzm[wv] = tr;
+        }
+        __syncthreads();
+        if ((tid & (HJD_WRITE_WG - 1u)) == 0) {
+            const uint32_t h = tid / HJD_WRITE_WG, w0 = h * (HJD_WRITE_WG / 64);
+            uint32_t sb = 0, sr = 0;
+            for (uint32_t q = 0; q < HJD_WRITE_WG / 64; q++) {
+                sb += s_lp[w0 + q];
+                sr += s_lzm[w0 + q];
+            }
+            if (wg * 2u + h < im.nwritewg) P.wgsum[im.writewg0 + wg * 2u + h] = make_uint2(sb, sr);
+            if (wg == 0 && h == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
+        }
+    }
     if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
     if (owned) {
         P.substate[g] = make_uint4(s_ep[tid], s_ezm[tid], up, uzm);
@@ -467,6 +491,7 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P) { sync_body<0
 
 // the repair pass is its own kernel symbol so that profiles tell the two apart
 __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair(HjdParams P) { sync_body<1>(P); }
+__global__ __launch_bounds__(HJD_SYNC_WG) void k_repair_totals(HjdParams P) { sync_body<2>(P); }
 
 // ---- stage 2: totals per final-pass workgroup ---------------------------------------------------
 // k_write places its outputs by exclusive prefix sums over the subsequences' block and record counts;
@@ -605,9 +630,12 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (mode == 0) {
         if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
-    } else {
+    } else if (mode == 1) {
         if (set_dyn_lds(reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
+    } else {
+        if (set_dyn_lds(reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
+        hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     }
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;

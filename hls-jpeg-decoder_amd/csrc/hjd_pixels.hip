@@ -44,7 +44,9 @@ __constant__ float c_cos[64] = {
 // saturates to 0..255; v_trunc_f32 followed by v_cvt_pk_u8_f32 (float -> u8 with saturation, written
 // into a chosen byte of a dword) gives the same byte for every finite input: truncation first makes
 // the value integral, so the conversion's own rounding never acts, negative values saturate to 0
-// like Clamp((int)x) does.  Checked exhaustively over all 2^24 inputs by k_color_table.
+// like Clamp((int)x) does.  (Without the v_trunc_f32 the conversion rounds to nearest and the exhaustive
+// device test fails — tried.)  k_color_table runs these functions over all 2^24 inputs the colour stage
+// can ever see (tests/test_gpu_parity.py::test_colour_stage_exhaustive).
 
 struct ChromaTerms {
     float a, b, c, d; // 1.402 cr', 0.34414 cb', 0.71414 cr', 1.772 cb'   (x' = x - 128)
@@ -69,8 +71,9 @@ __device__ __forceinline__ uint32_t put_u8(float x, uint32_t sel, uint32_t acc)
 
 // Four pixels -> the 12 bytes c0,g,c2 x 4 (c0 = R and c2 = B for the m_rgb layout, swapped for BMP).
 // y4 = four luma bytes; t0..t3 = chroma terms of the four pixels (4:2:x callers pass each pair twice).
+template <bool bgr>
 __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const ChromaTerms &t1, const ChromaTerms &t2,
-                                      const ChromaTerms &t3, bool bgr, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+                                      const ChromaTerms &t3, uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
     const float y0 = (float)(y4 & 0xFF), y1 = (float)((y4 >> 8) & 0xFF), y2 = (float)((y4 >> 16) & 0xFF), y3 = (float)(y4 >> 24);
     const float r0 = y0 + t0.a, g0 = (y0 - t0.b) - t0.c, b0 = y0 + t0.d;
@@ -84,6 +87,84 @@ __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const 
     d0 = put_u8(f1, 3, put_u8(l0, 2, put_u8(g0, 1, put_u8(f0, 0, 0u))));
     d1 = put_u8(g2, 3, put_u8(f2, 2, put_u8(l1, 1, put_u8(g1, 0, 0u))));
     d2 = put_u8(l3, 3, put_u8(g3, 2, put_u8(f3, 1, put_u8(l2, 0, 0u))));
+}
+
+// Phase 3 of k_idct_color: nearest-neighbour chroma (loadjpg.cpp:911-912), colour, clip at the image edge
+// (:906-909), then either the m_rgb layout or the WriteBMP24 layout (openjpg.cpp:555-568).  A thread owns one
+// 4-pixel column of the group for good and walks chroma rows; everything that depends on the column only is
+// computed once, and the chroma products once per chroma sample row (they serve vf luma rows).
+template <bool BMP>
+__device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
+                                            uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
+{
+    const uint32_t W = im.width, H = im.height, hf = im.hf, vf = im.vf, nb = im.nb, nby = im.nby;
+    const uint32_t stride = im.out_stride;
+    const uint32_t mw = 8 * hf, mh = 8 * vf;
+    // hf, vf are 1, 2 or 4 (hjd_parse_header): index arithmetic is shifts and masks.  The unit grid is padded to
+    // HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields of the thread index.
+    const uint32_t lhf = hf >> 1, lvf = vf >> 1; // log2 for 1, 2, 4
+    const uint32_t lupr = 5 + lhf;               // log2(4-pixel units per padded row) = log2(HJD_GROUP_MCUS * 2 * hf)
+    const uint32_t ux = tid & ((1u << lupr) - 1u);
+    const uint32_t px = ux * 4;
+    const uint32_t k = px >> (3 + lhf), xin = px & (mw - 1u);
+    const uint32_t gxp = (mcu_first + k) * mw + xin;
+    if (ux < K * 2 * hf && gxp < W) { // loadjpg.cpp:907
+        const uint32_t nvalid = min(4u, W - gxp);
+        const uint32_t ycol = k * nb + (xin >> 3), ybyte = xin & 7u;
+        const uint8_t *pcb0 = &s_pix[k * nb + nby][0], *pcr0 = &s_pix[k * nb + nby + 1][0];
+        for (uint32_t cy = tid >> lupr; cy < 8u; cy += 256u >> lupr) {
+            ChromaTerms t0, t1, t2, t3;
+            if (hf == 2) { // pixels 0,1 and 2,3 share a chroma sample (cx = x/2)
+                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb0[cy * 8 + (xin >> 1)]);
+                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr0[cy * 8 + (xin >> 1)]);
+                t0 = t1 = chroma_terms(cb2 & 0xFF, cr2 & 0xFF);
+                t2 = t3 = chroma_terms(cb2 >> 8, cr2 >> 8);
+            } else if (hf == 4) {
+                t0 = t1 = t2 = t3 = chroma_terms(pcb0[cy * 8 + (xin >> 2)], pcr0[cy * 8 + (xin >> 2)]);
+            } else {
+                const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb0[cy * 8 + xin]);
+                const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr0[cy * 8 + xin]);
+                t0 = chroma_terms(cb4 & 0xFF, cr4 & 0xFF);
+                t1 = chroma_terms((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF);
+                t2 = chroma_terms((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF);
+                t3 = chroma_terms(cb4 >> 24, cr4 >> 24);
+            }
+            for (uint32_t dy = 0; dy < vf; dy++) {
+                const uint32_t row = (cy << lvf) + dy;
+                const uint32_t gy = mrow * mh + row;
+                if (gy >= H) break; // loadjpg.cpp:908
+                const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[ycol + ((row >> 3) << lhf)][(row & 7) * 8 + ybyte]);
+                uint32_t d0, d1, d2;
+                rgb12<BMP>(ypix, t0, t1, t2, t3, d0, d1, d2);
+                uint8_t *dst = BMP ? out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3 : out + (size_t)gy * stride + (size_t)gxp * 3;
+                if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
+                    struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
+                    Px12 v12 = {d0, d1, d2};
+                    *reinterpret_cast<Px12 *>(dst) = v12; // one 12-byte store: a wave writes 768 contiguous bytes
+                } else {
+                    const uint32_t dd[3] = {d0, d1, d2};
+                    for (uint32_t j = 0; j < nvalid * 3; j++) dst[j] = (uint8_t)(dd[j >> 2] >> ((j & 3) * 8));
+                }
+                if (BMP && gxp + nvalid == W) // row padding (openjpg.cpp:563-567), written as zeros
+                    for (uint32_t q = 3 * W; q < stride; q++) out[54 + (size_t)(H - 1 - gy) * stride + q] = 0;
+            }
+        }
+    }
+    if (BMP && lg == 0 && tid < 54) {
+        // stBMFH (openjpg.cpp:507-547): 'BM', file size, 0, 0, 54, 40, W, H, planes 1, 24 bpp, rest 0
+        const uint32_t fsz = W * H * 3 + H * (stride - 3 * W) + 54;
+        uint32_t v = 0;
+        if (tid == 0) v = 'B';
+        else if (tid == 1) v = 'M';
+        else if (tid >= 2 && tid < 6) v = (fsz >> (8 * (tid - 2))) & 0xFF;
+        else if (tid == 10) v = 54;
+        else if (tid == 14) v = 40;
+        else if (tid >= 18 && tid < 22) v = (W >> (8 * (tid - 18))) & 0xFF;
+        else if (tid >= 22 && tid < 26) v = (H >> (8 * (tid - 22))) & 0xFF;
+        else if (tid == 26) v = 1;
+        else if (tid == 28) v = 24;
+        out[tid] = (uint8_t)v;
+    }
 }
 
 // ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
@@ -108,7 +189,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;
     const uint32_t mcu_first = gx * HJD_GROUP_MCUS;
     const uint32_t K = min((uint32_t)HJD_GROUP_MCUS, im.mcux - mcu_first);
-    const uint32_t nb = im.nb, nby = im.nby, hf = im.hf, vf = im.vf;
+    const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t KB = K * nb;
     const uint32_t lnby = nby >> 1; // log2 for 1, 2, 4
     const uint32_t nluma = K << lnby;
@@ -151,7 +232,11 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     // (short)(int) cast.
     {
         const uint32_t *rec = P.rec + im.rec_off;
-        const uint32_t r0 = s_range[0], r1 = s_range[1];
+        // a group holds at most 63 records per block plus the padding at subsequence ends; entries left over
+        // from a run that failed half-way (the image then carries an error status) must not turn this loop
+        // into a walk over the whole record array
+        const uint32_t r0 = s_range[0];
+        const uint32_t r1 = min(s_range[1], r0 + MAXGB * 64u + 1024u);
         const uint32_t b0 = (uint32_t)(gm.y - im.blk_off);
         for (uint32_t t = (r0 & ~3u) + tid * 4u; t < r1; t += 1024u) {
             const uint4 q = *reinterpret_cast<const uint4 *>(rec + t);
@@ -206,96 +291,39 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
                     }
                 }
             }
+            // (int)(0.25*sum), then short += 128, then Clamp (loadjpg.cpp:123,136-137,219).  The short only wraps
+            // for |0.25*sum| >= 32640; below that Clamp((short)((int)t + 128)) == saturate_u8(trunc(t) + 128),
+            // which is what v_cvt_pk_u8_f32 computes from the integral float trunc(t) + 128 (exact below 2^23).
+            float big = 0.0f;
 #pragma unroll
             for (int y = 0; y < 8; y++) {
-                // (int)(0.25*sum) then short +128 then Clamp (loadjpg.cpp:123,136-137,219)
-                // (int16)((int16)t + 128) == (int16)(t + 128): one wrap
-                const int ta = (int)(int16_t)((int)(acc0[y] * 0.25f) + 128);
-                const int tb = (int)(int16_t)((int)(acc1[y] * 0.25f) + 128);
-                const uint32_t pa = (uint32_t)min(max(ta, 0), 255), pb = (uint32_t)min(max(tb, 0), 255);
-                *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)(pa | (pb << 8));
+                acc0[y] = acc0[y] * 0.25f;
+                acc1[y] = acc1[y] * 0.25f;
+                big = fmaxf(big, fmaxf(fabsf(acc0[y]), fabsf(acc1[y])));
+            }
+            if (big < 32000.0f) {
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const uint32_t pp = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(acc1[y]) + 128.0f, 1,
+                                        __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(acc0[y]) + 128.0f, 0, 0u));
+                    *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)pp;
+                }
+            } else { // extreme coefficients: the reference's int16 arithmetic, literally
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const int ta = (int)(int16_t)((int)(int16_t)(int)acc0[y] + 128);
+                    const int tb = (int)(int16_t)((int)(int16_t)(int)acc1[y] + 128);
+                    const uint32_t pa = (uint32_t)min(max(ta, 0), 255), pb = (uint32_t)min(max(tb, 0), 255);
+                    *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)(pa | (pb << 8));
+                }
             }
         }
     }
     __syncthreads();
 
-    // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932): nearest-neighbour chroma, clip at
-    // the image edge, then either m_rgb layout or WriteBMP24 layout (openjpg.cpp:555-568)
-    {
-        const uint32_t W = im.width, H = im.height;
-        const uint32_t mw = 8 * hf, mh = 8 * vf;
-        // hf, vf are 1, 2 or 4 (hjd_parse_header): all index arithmetic below is shifts and masks.  The
-        // unit grid is padded to HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields.
-        const uint32_t lhf = hf >> 1, lvf = vf >> 1; // log2 for 1, 2, 4
-        const uint32_t upr = K * 2 * hf;             // valid 4-pixel units per row
-        const uint32_t lupr = 5 + lhf;               // log2(HJD_GROUP_MCUS * 2 * hf)
-        const uint32_t nunits = mh << lupr;
-        uint8_t *out = P.out + im.out_off;
-        const bool bmp = im.out_format == 1;
-        const uint32_t stride = im.out_stride;
-        for (uint32_t t = tid; t < nunits; t += 256) {
-            const uint32_t row = t >> lupr, ux = t & ((1u << lupr) - 1u);
-            if (ux >= upr) continue;
-            const uint32_t px = ux * 4;
-            const uint32_t k = px >> (3 + lhf), xin = px & (mw - 1u);
-            const uint32_t gy = mrow * mh + row;
-            const uint32_t gxp = (mcu_first + k) * mw + xin;
-            if (gy >= H || gxp >= W) continue; // loadjpg.cpp:907-908
-            const uint32_t yblk = k * nb + ((row >> 3) << lhf) + (xin >> 3);
-            const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[yblk][(row & 7) * 8 + (xin & 7)]);
-            const uint32_t cy = row >> lvf;
-            const uint8_t *pcb = &s_pix[k * nb + nby][cy * 8];
-            const uint8_t *pcr = &s_pix[k * nb + nby + 1][cy * 8];
-            uint32_t d0, d1, d2;
-            if (hf == 2) {
-                // 4:2:x — pixels 0,1 and 2,3 share a chroma sample (cx = x/2, loadjpg.cpp:912): the four
-                // chroma products are formed once per sample; every operation is the same fp32 operation
-                // ConvertYCrCbtoRGB performs
-                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb[xin >> 1]);
-                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr[xin >> 1]);
-                const ChromaTerms ta = chroma_terms(cb2 & 0xFF, cr2 & 0xFF), tb = chroma_terms(cb2 >> 8, cr2 >> 8);
-                rgb12(ypix, ta, ta, tb, tb, bmp, d0, d1, d2);
-            } else if (hf == 4) {
-                const ChromaTerms ta = chroma_terms(pcb[xin >> 2], pcr[xin >> 2]);
-                rgb12(ypix, ta, ta, ta, ta, bmp, d0, d1, d2);
-            } else {
-                const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb[xin]);
-                const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr[xin]);
-                rgb12(ypix, chroma_terms(cb4 & 0xFF, cr4 & 0xFF), chroma_terms((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF),
-                      chroma_terms((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF), chroma_terms(cb4 >> 24, cr4 >> 24), bmp, d0, d1, d2);
-            }
-            const uint32_t nvalid = min(4u, W - gxp);
-            uint8_t *dst;
-            if (bmp) dst = out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3;
-            else dst = out + (size_t)gy * stride + (size_t)gxp * 3;
-            if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
-                struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
-                Px12 v12 = {d0, d1, d2};
-                *reinterpret_cast<Px12 *>(dst) = v12; // one 12-byte store: a wave writes 768 contiguous bytes
-            } else {
-                const uint32_t dd[3] = {d0, d1, d2};
-                for (uint32_t j = 0; j < nvalid * 3; j++) dst[j] = (uint8_t)(dd[j >> 2] >> ((j & 3) * 8));
-            }
-            if (bmp && gxp + nvalid == W) { // row padding (openjpg.cpp:563-567), written as zeros
-                for (uint32_t q = 3 * W; q < stride; q++) out[54 + (size_t)(H - 1 - gy) * stride + q] = 0;
-            }
-        }
-        if (bmp && lg == 0 && tid < 54) {
-            // stBMFH (openjpg.cpp:507-547): 'BM', file size, 0, 0, 54, 40, W, H, planes 1, 24 bpp, rest 0
-            const uint32_t fsz = W * H * 3 + H * (stride - 3 * W) + 54;
-            uint32_t v = 0;
-            if (tid == 0) v = 'B';
-            else if (tid == 1) v = 'M';
-            else if (tid >= 2 && tid < 6) v = (fsz >> (8 * (tid - 2))) & 0xFF;
-            else if (tid == 10) v = 54;
-            else if (tid == 14) v = 40;
-            else if (tid >= 18 && tid < 22) v = (W >> (8 * (tid - 18))) & 0xFF;
-            else if (tid >= 22 && tid < 26) v = (H >> (8 * (tid - 22))) & 0xFF;
-            else if (tid == 26) v = 1;
-            else if (tid == 28) v = 24;
-            out[tid] = (uint8_t)v;
-        }
-    }
+    // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932) + output layout
+    if (im.out_format == 1) color_store<true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    else color_store<false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
 }
 
 // Test hook: the colour stage, alone, over every (Y, Cb, Cr) triple.  Output: 3 bytes
@@ -305,8 +333,8 @@ __global__ __launch_bounds__(256) void k_color_table(uint8_t *out)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x; // (Y, Cb, quarter of Cr): four triples with consecutive Cr
     const uint32_t y = t >> 14, cb = (t >> 6) & 0xFF, cr0 = (t & 63u) * 4u;
     uint32_t d0, d1, d2;
-    rgb12(y * 0x01010101u, chroma_terms(cb, cr0), chroma_terms(cb, cr0 + 1), chroma_terms(cb, cr0 + 2), chroma_terms(cb, cr0 + 3),
-          false, d0, d1, d2);
+    rgb12<false>(y * 0x01010101u, chroma_terms(cb, cr0), chroma_terms(cb, cr0 + 1), chroma_terms(cb, cr0 + 2), chroma_terms(cb, cr0 + 3),
+                 d0, d1, d2);
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)((y << 16) | (cb << 8) | cr0) * 3u);
     dst[0] = d0;
     dst[1] = d1;

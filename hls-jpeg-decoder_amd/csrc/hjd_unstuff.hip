@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
     if (threadIdx.x == 0) {
         P.chunk_kept[c] = total;
         P.chunk_mark[c] = mtotal;
+        if (c == im.chunk0) { // a new run of the image starts here: clear what the later kernels accumulate into
+            HjdImageState z = {};
+            P.st[ii] = z;
+        }
     }
 }
 

@@ -54,9 +54,10 @@ struct DeviceGuard {
 
 struct hjd_decoder {
     int device = 0;
-    uint32_t subseq_bits = 1024;
-    int sync_launches = 3; // one synchronisation launch + two repair launches (the second is empty unless a
-                           // repaired chain ran across the border of the first one's waves)
+    uint32_t subseq_bits = 2048;
+    int sync_launches = 2; // one synchronisation launch + one repair launch (a gate that returns at once unless a
+                           // workgroup's 16 kbit of warm-up were not enough; whatever it leaves is caught by
+                           // k_write's induction check and repaired from the host)
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
@@ -221,7 +222,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     d->device = device;
     if (opt) {
         if (opt->subseq_bits) {
-            if (opt->subseq_bits < 64 || opt->subseq_bits > 2048 || (opt->subseq_bits & (opt->subseq_bits - 1))) {
+            if (opt->subseq_bits < 64 || opt->subseq_bits > 4096 || (opt->subseq_bits & (opt->subseq_bits - 1))) {
                 delete d;
                 hjd_set_last_status(HJD_ERR_ARG);
                 return nullptr;
@@ -232,9 +233,10 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
-    if (e && atoi(e) >= 64 && atoi(e) <= 2048 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
-    {   // warm-up: ~8192 bits of look-back, which a wrong start state does not survive in practice
-        uint32_t k = 8192 / d->subseq_bits;
+    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
+    {   // warm-up: ~16384 bits of look-back, which a wrong start state does not survive in practice (measured
+        // survival on the q85 bench content: 30 % after 1024 bits, 8 % after 2048, about x0.27 per further 1024)
+        uint32_t k = 16384 / d->subseq_bits;
         d->sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
         const char *ek = getenv("HJD_SYNC_OVERLAP");
         if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) d->sync_overlap = (uint32_t)atoi(ek);
@@ -617,7 +619,6 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     P.off_img = (uint32_t)r.i0;
     P.off_dcchunk = r.dc0;
     P.off_group = r.group0;
-    const uint32_t nimg = (uint32_t)(r.i1 - r.i0);
     int k = 0;
     auto mark = [&](const char *name) -> int {
         if (names) {
@@ -630,24 +631,20 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         return HJD_OK;
     };
     int rc;
+    const int nrep = b->dec->sync_launches - 1; // repair launches; the last one also leaves k_write's totals
     if (!from_resync) {
-        if ((rc = mark("reset"))) return rc;
-        HIPCHK(hipMemsetAsync(b->d_st + r.i0, 0, sizeof(HjdImageState) * nimg, s));
-        if ((rc = mark("unstuff"))) return rc;
+        if ((rc = mark("unstuff"))) return rc; // k_unstuff_count also clears the per-image state
         if (hjd_launch_unstuff(P, r.nchunk, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_sync"))) return rc;
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_repair"))) return rc;
-        for (int l = 1; l < b->dec->sync_launches; l++)
-            if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
+        for (int l = 0; l < nrep; l++)
+            if (hjd_launch_sync(P, r.nrepwg, l + 1 == nrep ? 2 : 1, s)) return HJD_ERR_INTERNAL;
+        if (nrep <= 0 && hjd_launch_scan(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     } else {
         if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
-        if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_sync(P, r.nrepwg, 2, s)) return HJD_ERR_INTERNAL;
     }
-    if ((rc = mark("scan"))) return rc;
-    if (hjd_launch_scan(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
-    if ((rc = mark("blk_clear"))) return rc; // stale offsets must never outlive a run that fails half-way
-    HIPCHK(hipMemsetAsync(b->d_blk + r.blk0, 0, sizeof(uint4) * r.nblk, s));
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
