@@ -284,7 +284,7 @@ def main():
 
     # end to end on this rank (never `value`): host JPEG bytes -> host RGB bytes through the pipelined entry point
     e2e = None
-    if rank == 0 and not args.no_end_to_end and hasattr(dec, "decode_host_pipelined"):
+    if rank == 0 and not args.no_end_to_end and hasattr(dec, "decode_host_pipelined_bench"):
         e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
 
     dt, total_pixels = shard.agree(dt, pixels, device="cuda" if backend == "nccl" else "cpu")  # MAX of time, SUM of pixels

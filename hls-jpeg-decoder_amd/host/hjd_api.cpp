@@ -61,6 +61,20 @@ struct hjd_decoder {
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
+    // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
+    // k+1's upload and chunk k-1's download run beside chunk k's kernels
+    struct Slot {
+        hjd_batch *b = nullptr;
+        hipEvent_t up_done = nullptr, run_done = nullptr, down_done = nullptr;
+        int first = 0, count = 0;
+        bool busy = false;
+        uint8_t *h_out = nullptr; // pinned staging for outputs whose destination is pageable memory
+        size_t h_out_cap = 0;
+        std::vector<uint8_t> direct; // per image of the chunk: copied straight to the caller's (pinned) buffer
+    };
+    Slot slot[3];
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
+    std::mutex pipe_mu;
 };
 
 struct hjd_batch {
@@ -103,6 +117,12 @@ struct hjd_batch {
     int16_t *d_dca = nullptr;
     uint32_t *d_rec = nullptr;
     uint32_t *d_maps = nullptr; // workgroup -> image tables of all kernels, one allocation
+    // A batch object can be re-prepared in place (hjd_batch_reset): slabs are only re-allocated when the new
+    // contents need more than they hold.  h_stage = pinned host staging for everything uploaded (scan bytes,
+    // image descriptors, tables, maps), so that the uploads are true asynchronous copies.
+    std::map<const void *, size_t> cap; // capacity in bytes per slab, keyed by the address of the slab pointer
+    uint8_t *h_stage = nullptr;
+    size_t h_stage_cap = 0;
     HjdParams P{};
     hipEvent_t ev[HJD_MAX_STAGES + 1] = {};
     bool have_events = false;
@@ -254,12 +274,48 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     return d;
 }
 
-extern "C" void hjd_decoder_destroy(hjd_decoder *d) { delete d; }
+extern "C" void hjd_batch_destroy(hjd_batch *b);
+
+extern "C" void hjd_decoder_destroy(hjd_decoder *d)
+{
+    if (!d) return;
+    {
+        DeviceGuard g(d->device);
+        for (auto &sl : d->slot) {
+            if (sl.b) hjd_batch_destroy(sl.b);
+            if (sl.up_done) (void)hipEventDestroy(sl.up_done);
+            if (sl.run_done) (void)hipEventDestroy(sl.run_done);
+            if (sl.down_done) (void)hipEventDestroy(sl.down_done);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+        }
+        if (d->s_up) (void)hipStreamDestroy(d->s_up);
+        if (d->s_run) (void)hipStreamDestroy(d->s_run);
+        if (d->s_down) (void)hipStreamDestroy(d->s_down);
+    }
+    delete d;
+}
 
 // ---- batch --------------------------------------------------------------------------------------
 
+// (Re)allocates *p when it holds less than `bytes`; keeps it otherwise.
+template <class T>
+static int slab_reserve(hjd_batch *b, T *&p, size_t bytes)
+{
+    if (bytes < 16) bytes = 16;
+    size_t &c = b->cap[(const void *)&p];
+    if (p && c >= bytes) return HJD_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    c = 0;
+    const size_t want = bytes + bytes / 16; // a little head-room: chunks of a stream of batches differ slightly
+    HIPCHK(hipMalloc(&p, want));
+    c = want;
+    return HJD_OK;
+}
+
 static void batch_free_device(hjd_batch *b)
 {
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
     (void)hipFree(b->d_img);
     (void)hipFree(b->d_st);
     (void)hipFree(b->d_tabs);
@@ -295,9 +351,19 @@ extern "C" void hjd_batch_destroy(hjd_batch *b)
     delete b;
 }
 
-static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
+// Lays the images out, makes sure the slabs are large enough and enqueues the uploads on `up` (all of them
+// asynchronous copies out of the batch's pinned staging buffer: nothing of the caller's memory is referenced
+// once this returns).  Usable on a fresh batch and on one that has been used before.
+static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, hipStream_t up)
 {
     hjd_decoder *d = b->dec;
+    b->img.clear();
+    b->out_bytes.clear();
+    b->hdr_bytes.clear();
+    b->ranges.clear();
+    b->nchunks = b->nsub = b->nsyncwg = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
+    b->pixels = b->alg_bytes = b->scan_bytes = 0;
+    b->resyncs = 0;
     DeviceGuard guard(d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     const uint32_t S = d->subseq_bits;
@@ -424,33 +490,29 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     b->state.assign(b->nimg, HjdImageState{});
     if (!b->nimg) return HJD_OK;
 
-    // upload
-    std::vector<uint8_t> raw(raw_cur, 0);
-    for (int i = 0; i < b->n; i++) {
-        int di = b->dev_index[i];
-        if (di < 0) continue;
-        memcpy(raw.data() + b->img[di].raw_off, parsed[i].stream, parsed[i].stream_len);
-    }
-    HIPCHK(hipMalloc(&b->d_img, sizeof(HjdImage) * b->nimg));
-    HIPCHK(hipMalloc(&b->d_st, sizeof(HjdImageState) * b->nimg));
-    HIPCHK(hipMalloc(&b->d_tabs, sizeof(HjdTableSet) * tabs.size()));
-    HIPCHK(hipMalloc(&b->d_raw, raw_cur));
-    HIPCHK(hipMalloc(&b->d_ustream, us_cur));
-    HIPCHK(hipMalloc(&b->d_out, out_cur ? out_cur : 4));
-    HIPCHK(hipMalloc(&b->d_chunk_kept, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
-    HIPCHK(hipMalloc(&b->d_chunk_mark, sizeof(uint32_t) * (b->nchunks ? b->nchunks : 1)));
-    HIPCHK(hipMalloc(&b->d_mpos, sizeof(uint32_t) * (b->nmarks + 1)));
-    HIPCHK(hipMalloc(&b->d_mval, b->nmarks + 1));
-    HIPCHK(hipMalloc(&b->d_substate, sizeof(uint4) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMalloc(&b->d_subcnt, sizeof(uint32_t) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMalloc(&b->d_wgsum, sizeof(uint2) * (b->nwritewg ? b->nwritewg : 1)));
-    HIPCHK(hipMalloc(&b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
-    HIPCHK(hipMalloc(&b->d_blk, sizeof(uint4) * (blk_cur + 1)));
-    HIPCHK(hipMalloc(&b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
-    HIPCHK(hipMalloc(&b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
-    HIPCHK(hipMemset(b->d_blk, 0, sizeof(uint4) * (blk_cur + 1)));
+    int rcs = HJD_OK;
+    auto need = [&](int r) { if (r != HJD_OK && rcs == HJD_OK) rcs = r; };
+    need(slab_reserve(b, b->d_img, sizeof(HjdImage) * b->nimg));
+    need(slab_reserve(b, b->d_st, sizeof(HjdImageState) * b->nimg));
+    need(slab_reserve(b, b->d_tabs, sizeof(HjdTableSet) * tabs.size()));
+    need(slab_reserve(b, b->d_raw, raw_cur));
+    need(slab_reserve(b, b->d_ustream, us_cur));
+    need(slab_reserve(b, b->d_out, out_cur));
+    need(slab_reserve(b, b->d_chunk_kept, sizeof(uint32_t) * b->nchunks));
+    need(slab_reserve(b, b->d_chunk_mark, sizeof(uint32_t) * b->nchunks));
+    need(slab_reserve(b, b->d_mpos, sizeof(uint32_t) * (b->nmarks + 1)));
+    need(slab_reserve(b, b->d_mval, b->nmarks + 1));
+    need(slab_reserve(b, b->d_substate, sizeof(uint4) * b->nsub));
+    need(slab_reserve(b, b->d_subcnt, sizeof(uint32_t) * b->nsub));
+    need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
+    need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
+    need(slab_reserve(b, b->d_blk, sizeof(uint4) * (blk_cur + 1)));
+    need(slab_reserve(b, b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
+    need(slab_reserve(b, b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
+    if (rcs != HJD_OK) return rcs;
+    HIPCHK(hipMemsetAsync(b->d_blk, 0, sizeof(uint4) * (blk_cur + 1), up));
+    std::vector<uint32_t> maps;
     {   // workgroup -> image for every kernel's workgroup numbering; IDCT groups also get their first block
-        std::vector<uint32_t> maps;
         size_t off_chunk = 0, off_sync, off_rep, off_write, off_dc, off_group;
         auto fill = [&](uint32_t HjdImage::*first, uint32_t HjdImage::*count) {
             const size_t at = maps.size();
@@ -478,8 +540,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
             }
         }
         if (blk_cur >= 0xFFFFFFFFull) return HJD_ERR_UNSUPPORTED;
-        HIPCHK(hipMalloc(&b->d_maps, sizeof(uint32_t) * (maps.size() + 2)));
-        HIPCHK(hipMemcpy(b->d_maps, maps.data(), sizeof(uint32_t) * maps.size(), hipMemcpyHostToDevice));
+        need(slab_reserve(b, b->d_maps, sizeof(uint32_t) * (maps.size() + 2)));
+        if (rcs != HJD_OK) return rcs;
         b->P.map_chunk = b->d_maps + off_chunk;
         b->P.map_syncwg = b->d_maps + off_sync;
         b->P.map_repwg = b->d_maps + off_rep;
@@ -487,13 +549,38 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
         b->P.map_dcchunk = b->d_maps + off_dc;
         b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
     }
-    HIPCHK(hipMemcpy(b->d_img, b->img.data(), sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_tabs, tabs.data(), sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(b->d_raw, raw.data(), raw_cur, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(b->d_ustream, 0, us_cur));
-    HIPCHK(hipMemset(b->d_st, 0, sizeof(HjdImageState) * b->nimg));
-    HIPCHK(hipMemset(b->d_substate, 0, sizeof(uint4) * (b->nsub ? b->nsub : 1)));
-    HIPCHK(hipMemset(b->d_subcnt, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1)));
+    {   // stage everything that goes up in ONE pinned buffer: [scan bytes | image descriptors | tables | maps]
+        const size_t o_img = align_up(raw_cur, 256), o_tab = align_up(o_img + sizeof(HjdImage) * b->nimg, 256);
+        const size_t o_map = align_up(o_tab + sizeof(HjdTableSet) * tabs.size(), 256);
+        const size_t total = o_map + sizeof(uint32_t) * maps.size() + 256;
+        if (total > b->h_stage_cap) {
+            if (b->h_stage) (void)hipHostFree(b->h_stage);
+            b->h_stage = nullptr;
+            b->h_stage_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&b->h_stage, total + total / 16, hipHostMallocDefault));
+            b->h_stage_cap = total + total / 16;
+        }
+        uint8_t *h = b->h_stage;
+        for (int i = 0; i < b->n; i++) {
+            const int di = b->dev_index[i];
+            if (di < 0) continue;
+            const HjdImage &im = b->img[di];
+            memcpy(h + im.raw_off, parsed[i].stream, parsed[i].stream_len);
+            const size_t slab = align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
+            memset(h + im.raw_off + parsed[i].stream_len, 0, slab - parsed[i].stream_len); // the kernels read whole 16-byte pieces
+        }
+        memcpy(h + o_img, b->img.data(), sizeof(HjdImage) * b->nimg);
+        memcpy(h + o_tab, tabs.data(), sizeof(HjdTableSet) * tabs.size());
+        memcpy(h + o_map, maps.data(), sizeof(uint32_t) * maps.size());
+        HIPCHK(hipMemcpyAsync(b->d_raw, h, raw_cur, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpyAsync(b->d_img, h + o_img, sizeof(HjdImage) * b->nimg, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpyAsync(b->d_tabs, h + o_tab, sizeof(HjdTableSet) * tabs.size(), hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpyAsync(b->d_maps, h + o_map, sizeof(uint32_t) * maps.size(), hipMemcpyHostToDevice, up));
+    }
+    HIPCHK(hipMemsetAsync(b->d_ustream, 0, us_cur, up));
+    HIPCHK(hipMemsetAsync(b->d_st, 0, sizeof(HjdImageState) * b->nimg, up));
+    HIPCHK(hipMemsetAsync(b->d_substate, 0, sizeof(uint4) * (b->nsub ? b->nsub : 1), up));
+    HIPCHK(hipMemsetAsync(b->d_subcnt, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1), up));
 
     HjdParams &P = b->P;
     P.img = b->d_img;
@@ -548,11 +635,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
             i0 = i1;
         }
         if (b->ranges.size() > 1) {
-            b->istreams.resize(b->ranges.size());
-            b->join_ev.resize(b->ranges.size());
-            for (auto &st : b->istreams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            for (auto &e : b->join_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+            while (b->istreams.size() < b->ranges.size()) {
+                hipStream_t st;
+                hipEvent_t e;
+                HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                b->istreams.push_back(st);
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                b->join_ev.push_back(e);
+            }
+            if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         }
     }
     P.subseq_bits = S;
@@ -572,25 +663,56 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed)
     return HJD_OK;
 }
 
+static int batch_reset_parsed(hjd_batch *b, int n, const std::vector<hjd_jpeg_data> &parsed, const std::vector<int> &pstatus,
+                              int out_format, int *status, hipStream_t up, bool wait)
+{
+    b->n = n;
+    b->out_format = out_format;
+    b->parse_status = pstatus;
+    b->dev_index.assign(n, -1);
+    b->tev_n.clear();
+    int rc = batch_build(b, parsed, up);
+    if (rc == HJD_OK && wait && hipStreamSynchronize(up) != hipSuccess) rc = HJD_ERR_INTERNAL;
+    if (status)
+        for (int i = 0; i < n; i++) status[i] = b->parse_status[i];
+    return rc;
+}
+
 static hjd_batch *batch_from_parsed(hjd_decoder *d, int n, const std::vector<hjd_jpeg_data> &parsed,
                                     const std::vector<int> &pstatus, int out_format, int *status)
 {
     hjd_batch *b = new hjd_batch();
     b->dec = d;
     b->device = d->device;
-    b->n = n;
-    b->out_format = out_format;
-    b->parse_status = pstatus;
-    b->dev_index.assign(n, -1);
-    int rc = batch_build(b, parsed);
-    if (status)
-        for (int i = 0; i < n; i++) status[i] = b->parse_status[i];
+    const int rc = batch_reset_parsed(b, n, parsed, pstatus, out_format, status, nullptr, true);
     if (rc != HJD_OK) {
         hjd_set_last_status(rc);
         hjd_batch_destroy(b);
         return nullptr;
     }
     return b;
+}
+
+extern "C" hjd_batch *hjd_batch_create(hjd_decoder *d)
+{
+    if (!d) {
+        hjd_set_last_status(HJD_ERR_ARG);
+        return nullptr;
+    }
+    hjd_batch *b = new hjd_batch();
+    b->dec = d;
+    b->device = d->device;
+    return b;
+}
+
+extern "C" int hjd_batch_reset(hjd_batch *b, int n, const uint8_t *const *jpg, const size_t *jpg_len, int out_format,
+                               int *status, void *hip_stream)
+{
+    if (!b || n < 0 || (n && (!jpg || !jpg_len)) || (out_format != HJD_OUT_RGB && out_format != HJD_OUT_BMP)) return HJD_ERR_ARG;
+    std::vector<hjd_jpeg_data> parsed(n);
+    std::vector<int> pst(n);
+    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]) : HJD_ERR_ARG;
+    return batch_reset_parsed(b, n, parsed, pst, out_format, status, (hipStream_t)hip_stream, false);
 }
 
 extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
@@ -915,22 +1037,132 @@ extern "C" int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *
     return HJD_OK;
 }
 
+// ---- host to host, pipelined ---------------------------------------------------------------------
+// The file-in / file-out contract of the reference (openjpg.cpp:593-684) for a whole batch: host JPEG bytes in,
+// host RGB/BMP bytes out.  The batch is cut into chunks of about 12 MB of JPEG data; chunk k's header walk,
+// staging copy and H2D run while chunk k-1's kernels and chunk k-2's D2H are in flight (three streams, a ring
+// of three re-usable batch objects: no allocation once the ring has grown to the chunk size).  Outputs are
+// copied straight into the caller's buffers when those are pinned (hjd_host_alloc / hipHostMalloc /
+// hipHostRegister); pageable destinations go through pinned staging and a host memcpy.
+
+extern "C" void *hjd_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void hjd_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int pipe_retire(hjd_decoder *d, hjd_decoder::Slot &sl, uint8_t *const *out, const size_t *out_cap, int *status)
+{
+    if (!sl.busy) return HJD_OK;
+    sl.busy = false;
+    HIPCHK(hipEventSynchronize(sl.down_done));
+    std::vector<int> st(sl.count, 0);
+    const int before = sl.b->resyncs;
+    int rc = hjd_batch_finish(sl.b, d->s_run, st.data());
+    if (rc != HJD_OK) return rc;
+    const bool redo = sl.b->resyncs != before; // outputs changed after the download was enqueued (host re-synchronisation)
+    for (int k = 0; k < sl.count; k++) {
+        const int i = sl.first + k;
+        if (status) status[i] = st[k];
+        if (st[k] != HJD_OK) continue;
+        size_t off = 0, nb = 0;
+        hjd_batch_image_info(sl.b, k, nullptr, nullptr, &off, &nb);
+        if (redo) {
+            HIPCHK(hipMemcpy(out[i], sl.b->d_out + off, nb, hipMemcpyDeviceToHost));
+        } else if (!sl.direct[k]) {
+            memcpy(out[i], sl.h_out + off, nb);
+        }
+    }
+    return HJD_OK;
+}
+
 extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
                                      int out_format, uint8_t *const *out, const size_t *out_cap, int *status)
 {
-    if (!d || !out || !out_cap) return HJD_ERR_ARG;
-    std::vector<int> st(n, 0);
-    hjd_batch *b = hjd_batch_prepare(d, n, jpg, jpg_len, out_format, st.data());
-    if (!b) return hjd_last_status();
-    int rc = hjd_batch_run(b, nullptr);
-    if (rc == HJD_OK) rc = hjd_batch_finish(b, nullptr, st.data());
-    for (int i = 0; i < n && rc == HJD_OK; i++) {
-        if (st[i] != HJD_OK) continue;
-        int r = hjd_batch_download(b, i, out[i], out_cap[i]);
-        if (r != HJD_OK) st[i] = r;
+    if (!d || n < 0 || (n && (!jpg || !jpg_len || !out || !out_cap)) || (out_format != HJD_OUT_RGB && out_format != HJD_OUT_BMP))
+        return HJD_ERR_ARG;
+    std::lock_guard<std::mutex> lk(d->pipe_mu);
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
+    if (!d->s_up) {
+        HIPCHK(hipStreamCreateWithFlags(&d->s_up, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&d->s_run, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&d->s_down, hipStreamNonBlocking));
+        for (auto &sl : d->slot) {
+            HIPCHK(hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sl.run_done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sl.down_done, hipEventDisableTiming));
+            sl.b = hjd_batch_create(d);
+        }
     }
-    if (status) memcpy(status, st.data(), sizeof(int) * n);
-    hjd_batch_destroy(b);
+    const size_t chunk_bytes = 12u << 20;
+    int rc = HJD_OK, nslot = 0;
+    for (int i0 = 0; i0 < n && rc == HJD_OK;) {
+        int i1 = i0;
+        size_t acc = 0;
+        while (i1 < n && (i1 == i0 || (acc + jpg_len[i1] <= chunk_bytes && i1 - i0 < 64))) acc += jpg_len[i1++];
+        hjd_decoder::Slot &sl = d->slot[nslot++ % 3];
+        if ((rc = pipe_retire(d, sl, out, out_cap, status)) != HJD_OK) break; // the slot's previous chunk must be out first
+        sl.first = i0;
+        sl.count = i1 - i0;
+        std::vector<int> pst(sl.count, 0);
+        rc = hjd_batch_reset(sl.b, sl.count, jpg + i0, jpg_len + i0, out_format, pst.data(), d->s_up);
+        if (rc != HJD_OK) break;
+        HIPCHK(hipEventRecord(sl.up_done, d->s_up));
+        HIPCHK(hipStreamWaitEvent(d->s_run, sl.up_done, 0));
+        if ((rc = hjd_batch_run(sl.b, d->s_run)) != HJD_OK) break;
+        HIPCHK(hipEventRecord(sl.run_done, d->s_run));
+        HIPCHK(hipStreamWaitEvent(d->s_down, sl.run_done, 0));
+        sl.direct.assign(sl.count, 0);
+        size_t stage_need = 0;
+        for (int k = 0; k < sl.count; k++) {
+            size_t off = 0, nb = 0;
+            if (hjd_batch_image_info(sl.b, k, nullptr, nullptr, &off, &nb) != HJD_OK) continue; // did not parse: status says so
+            if (out_cap[i0 + k] < nb || !out[i0 + k]) {
+                rc = HJD_ERR_ARG;
+                break;
+            }
+            sl.direct[k] = is_pinned(out[i0 + k]) ? 1 : 0;
+            if (!sl.direct[k] && off + nb > stage_need) stage_need = off + nb;
+        }
+        if (rc != HJD_OK) break;
+        if (stage_need > sl.h_out_cap) {
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+            sl.h_out = nullptr;
+            sl.h_out_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&sl.h_out, stage_need + stage_need / 16, hipHostMallocDefault));
+            sl.h_out_cap = stage_need + stage_need / 16;
+        }
+        for (int k = 0; k < sl.count; k++) {
+            size_t off = 0, nb = 0;
+            if (hjd_batch_image_info(sl.b, k, nullptr, nullptr, &off, &nb) != HJD_OK) continue;
+            uint8_t *dst = sl.direct[k] ? out[i0 + k] : sl.h_out + off;
+            HIPCHK(hipMemcpyAsync(dst, sl.b->d_out + off, nb, hipMemcpyDeviceToHost, d->s_down));
+        }
+        HIPCHK(hipEventRecord(sl.down_done, d->s_down));
+        sl.busy = true;
+        i0 = i1;
+    }
+    for (auto &sl : d->slot) {
+        const int r = pipe_retire(d, sl, out, out_cap, status);
+        if (rc == HJD_OK) rc = r;
+    }
     return rc;
 }
 

@@ -166,9 +166,23 @@ int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
  * (0 in normal operation: the in-stream repair launch already settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);
 
-/* Convenience: decode N host JPEGs to N caller-provided host buffers (RGB or BMP). */
+/* A batch object that can be prepared again and again in place: slabs and pinned staging are re-allocated only
+ * when new contents need more than they hold.  hjd_batch_reset = the work of hjd_batch_prepare on an existing
+ * object, with every upload enqueued as an asynchronous copy on `hip_stream` (the caller orders later work
+ * after it; the caller's JPEG buffers are not referenced once the call returns). */
+hjd_batch *hjd_batch_create(hjd_decoder *d);
+int hjd_batch_reset(hjd_batch *b, int n, const uint8_t *const *jpg, const size_t *jpg_len, int out_format, int *status,
+                    void *hip_stream);
+
+/* Host JPEG bytes in, host RGB/BMP bytes out, for a whole batch: the file-in/file-out contract of the reference's
+ * ConvertJpgFile (openjpg.cpp:593-684) without the files.  Pipelined: header walk + H2D of chunk k+1, kernels of
+ * chunk k and D2H of chunk k-1 overlap on three streams.  out[i] receives image i (out_cap[i] >= its size);
+ * buffers from hjd_host_alloc (pinned) are written by the DMA engine directly, pageable ones through a pinned
+ * staging buffer and a host memcpy.  Returns when every output is complete. */
 int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
                           int out_format, uint8_t *const *out, const size_t *out_cap, int *status);
+void *hjd_host_alloc(size_t bytes); /* pinned host memory; NULL on failure */
+void hjd_host_free(void *p);
 
 /* Size helpers (WriteBMP24 arithmetic, openjpg.cpp:534-541). */
 size_t hjd_bmp_bytes(unsigned width, unsigned height);

@@ -432,6 +432,28 @@ def test_overflow_stress_blocks_through_the_back_end(hjd, dec):
     b.close()
 
 
+def test_pipelined_host_path_is_byte_identical(hjd, golden):
+    """hjd_decode_batch_host (header walk / H2D / kernels / D2H of successive chunks overlapped on three streams, ring of
+    re-used batch objects): same bytes as the resident-batch path, for pinned and for pageable destinations, RGB and
+    BMP, with failing images in the middle, over several chunks, and again on the re-used ring."""
+    d, man = golden
+    fx = _ok_fixtures(golden, restart=("none", "clean"))
+    big = [T.synth_jpeg(1920, 1080, 600 + k, 85, 2, 2) for k in range(4)] + [T.synth_jpeg(3840, 2160, 1000, 85, 2, 2)]
+    jpgs = [f[2] for f in fx] + [b"junk"] + big * 6 + [open(os.path.join(d, "pil_gray.jpg"), "rb").read()] + big * 3
+    dd = hjd.Decoder(0)
+    want = {}
+    for fmt in (hjd.OUT_RGB, hjd.OUT_BMP):
+        st0, ref = dd.decode(jpgs, fmt)
+        for pinned in (True, False, True):
+            st, outs = dd.decode_host(jpgs, fmt, pinned=pinned)
+            assert st == st0
+            for j, s, o, r in zip(jpgs, st, outs, ref):
+                if s == 0:
+                    assert np.array_equal(np.asarray(o), r.reshape(-1)), (fmt, pinned, len(j))
+    assert st0[len(fx)] == hjd.HJD_ERR_NOT_JPEG and sum(1 for s in st0 if s) == 2
+    dd.close()
+
+
 def test_two_ranks_share_one_batch(hjd, tmp_path):
     """The N > 1 code path on the hardware at hand: two ranks (own processes, gloo on 127.0.0.1, both on device 0)
     decode the two shards shard.partition() gives them of ONE 64-image mixed batch.  Union = every image exactly
