@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query",
 ]
 
 
@@ -39,6 +39,15 @@ class JpegData(ctypes.Structure):
                 ("stream", ctypes.c_void_p), ("stream_len", ctypes.c_size_t), ("restart_interval", ctypes.c_int),
                 ("restart_mcus", ctypes.c_uint), ("width", ctypes.c_uint), ("height", ctypes.c_uint),
                 ("hfactor", ctypes.c_uint8), ("vfactor", ctypes.c_uint8), ("header_bytes", ctypes.c_size_t)]
+
+
+class LayoutInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        "subseq_bits", "sync_overlap", "phase_words", "sync_wg", "write_wg", "group_mcus", "unstuff_chunk", "dc_chunk", "rec_run",
+        "nblocks", "mcux", "mcuy", "nb", "nchunks", "nsub_cap", "nsyncwg", "nrepwg", "nwritewg", "ndcchunk", "ngroups",
+        "groups_per_row", "mark_cap", "rec_cap", "out_stride", "lds_bytes_sync", "lds_bytes_write", "lds_state_word")] + \
+        [(n, ctypes.c_uint64) for n in ("raw_bytes", "ustream_bytes", "blk_entries", "dca_entries", "rec_entries", "out_bytes",
+                                        "substate_entries", "wgsum_entries", "dcsum_entries")]
 
 
 class Options(ctypes.Structure):
@@ -126,6 +135,8 @@ def lib():
     L.hjd_batch_create.argtypes = [vp]
     L.hjd_batch_reset.restype = ctypes.c_int
     L.hjd_batch_reset.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), ctypes.c_int, ip, vp]
+    L.hjd_layout_query.restype = ctypes.c_int
+    L.hjd_layout_query.argtypes = [ctypes.POINTER(JpegData), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LayoutInfo)]
     L.hjd_host_alloc.restype = vp
     L.hjd_host_alloc.argtypes = [sz]
     L.hjd_host_free.restype = None

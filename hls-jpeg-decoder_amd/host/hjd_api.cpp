@@ -42,6 +42,7 @@ struct DeviceGuard {
     bool ok = true;
     explicit DeviceGuard(int dev)
     {
+        if (dev < 0) return; // layout-only use (hjd_layout_query): no device involved
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
         else prev = -1; // nothing to restore
@@ -120,6 +121,7 @@ struct hjd_batch {
     // A batch object can be re-prepared in place (hjd_batch_reset): slabs are only re-allocated when the new
     // contents need more than they hold.  h_stage = pinned host staging for everything uploaded (scan bytes,
     // image descriptors, tables, maps), so that the uploads are true asynchronous copies.
+    bool dry = false;                   // hjd_layout_query: lay out only, touch no device
     std::map<const void *, size_t> cap; // capacity in bytes per slab, keyed by the address of the slab pointer
     uint8_t *h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -364,7 +366,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->nchunks = b->nsub = b->nsyncwg = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
-    DeviceGuard guard(d->device);
+    DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     const uint32_t S = d->subseq_bits;
     std::map<std::string, uint32_t> tab_index;
@@ -488,7 +490,22 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->nrec = rec_cur;
     b->out_total = out_cur;
     b->state.assign(b->nimg, HjdImageState{});
-    if (!b->nimg) return HJD_OK;
+    HjdParams &P = b->P;
+    P.subseq_bits = S;
+    P.log2_words = 0;
+    while ((32u << P.log2_words) < S) P.log2_words++;
+    P.sync_overlap = K;
+    {   // dynamic LDS of the entropy kernels: primary and secondary tables, per-workgroup state, then one
+        // staging window of phase_words + 2 words per lane
+        uint32_t wpp = d->phase_words;
+        if (wpp > S / 32) wpp = S / 32;
+        P.phase_words = wpp;
+        P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
+        P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
+        P.lds_bytes_sync = (P.lds_state_word + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_write = (P.lds_state_word + 48 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
+    }
+    if (b->dry || !b->nimg) return HJD_OK;
 
     int rcs = HJD_OK;
     auto need = [&](int r) { if (r != HJD_OK && rcs == HJD_OK) rcs = r; };
@@ -582,7 +599,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     HIPCHK(hipMemsetAsync(b->d_substate, 0, sizeof(uint4) * (b->nsub ? b->nsub : 1), up));
     HIPCHK(hipMemsetAsync(b->d_subcnt, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1), up));
 
-    HjdParams &P = b->P;
     P.img = b->d_img;
     P.st = b->d_st;
     P.tabs = b->d_tabs;
@@ -646,20 +662,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         }
     }
-    P.subseq_bits = S;
-    P.log2_words = 0;
-    while ((32u << P.log2_words) < S) P.log2_words++;
-    P.sync_overlap = K;
-    {   // dynamic LDS of the entropy kernels: primary and secondary tables, per-workgroup state, then one
-        // staging window of phase_words + 2 words per lane
-        uint32_t wpp = d->phase_words;
-        if (wpp > S / 32) wpp = S / 32;
-        P.phase_words = wpp;
-        P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
-        P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes_sync = (P.lds_state_word + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
-        P.lds_bytes_write = (P.lds_state_word + 48 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
-    }
     return HJD_OK;
 }
 
@@ -691,6 +693,69 @@ static hjd_batch *batch_from_parsed(hjd_decoder *d, int n, const std::vector<hjd
         return nullptr;
     }
     return b;
+}
+
+extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int sync_overlap, int out_format, hjd_layout_info *o)
+{
+    if (!j || !o) return HJD_ERR_ARG;
+    hjd_decoder d; // never touches a device
+    if (subseq_bits) d.subseq_bits = (uint32_t)subseq_bits;
+    {
+        uint32_t k = 16384 / d.subseq_bits;
+        d.sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
+        if (sync_overlap) d.sync_overlap = sync_overlap < 0 ? 0u : (uint32_t)sync_overlap;
+    }
+    hjd_batch b;
+    b.dec = &d;
+    b.dry = true;
+    b.n = 1;
+    b.out_format = out_format;
+    b.parse_status.assign(1, HJD_OK);
+    b.dev_index.assign(1, -1);
+    std::vector<hjd_jpeg_data> parsed(1, *j);
+    const int rc = batch_build(&b, parsed, nullptr);
+    if (rc != HJD_OK) return rc;
+    if (b.parse_status[0] != HJD_OK || b.img.empty()) return b.parse_status[0] ? b.parse_status[0] : HJD_ERR_UNSUPPORTED;
+    const HjdImage &im = b.img[0];
+    memset(o, 0, sizeof(*o));
+    o->subseq_bits = d.subseq_bits;
+    o->sync_overlap = d.sync_overlap;
+    o->phase_words = b.P.phase_words;
+    o->sync_wg = HJD_SYNC_WG;
+    o->write_wg = HJD_WRITE_WG;
+    o->group_mcus = HJD_GROUP_MCUS;
+    o->unstuff_chunk = HJD_UNSTUFF_CHUNK;
+    o->dc_chunk = HJD_DC_CHUNK;
+    o->rec_run = HJD_REC_RUN;
+    o->nblocks = im.nblocks;
+    o->mcux = im.mcux;
+    o->mcuy = im.mcuy;
+    o->nb = im.nb;
+    o->nchunks = im.nchunks;
+    o->nsub_cap = im.nsub_cap;
+    o->nsyncwg = im.nsyncwg;
+    o->nrepwg = im.nrepwg;
+    o->nwritewg = im.nwritewg;
+    o->ndcchunk = im.ndcchunk;
+    o->ngroups = im.ngroups;
+    o->groups_per_row = im.groups_per_row;
+    o->mark_cap = im.mark_cap;
+    o->rec_cap = im.rec_cap;
+    o->out_stride = im.out_stride;
+    o->raw_bytes = b.raw_bytes;
+    o->ustream_bytes = b.ustream_bytes;
+    o->blk_entries = b.nblk_entries + 1;       // what batch_build allocates
+    o->dca_entries = b.nblk_entries + 2;
+    o->rec_entries = b.nrec + HJD_REC_RUN;
+    o->out_bytes = b.out_total;
+    o->substate_entries = b.nsub;
+    o->wgsum_entries = b.nwritewg;
+    o->dcsum_entries = 3 * ((size_t)b.ndcchunks + 1);
+    o->lds_bytes_sync = b.P.lds_bytes_sync;
+    o->lds_bytes_write = b.P.lds_bytes_write;
+    o->lds_state_word = b.P.lds_state_word;
+    b.dec = nullptr;
+    return HJD_OK;
 }
 
 extern "C" hjd_batch *hjd_batch_create(hjd_decoder *d)

@@ -197,6 +197,19 @@ int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_t dst_elems
  * dst_cap >= 3 << 24 bytes (host memory). */
 int hjd_test_color_table(hjd_decoder *d, uint8_t *dst, size_t dst_cap);
 
+/* Test hook, no device needed: the HBM / LDS layout hjd_batch_prepare would give ONE image with these header fields
+ * and this scan length (only width, height, hfactor, vfactor, stream_len, restart fields and the table specs of
+ * `j` matter; `stream` must be non-NULL but is not read).  tests/test_layout_bounds.py recomputes from it the
+ * largest element every kernel may touch in every slab. */
+typedef struct hjd_layout_info {
+    uint32_t subseq_bits, sync_overlap, phase_words, sync_wg, write_wg, group_mcus, unstuff_chunk, dc_chunk, rec_run;
+    uint32_t nblocks, mcux, mcuy, nb, nchunks, nsub_cap, nsyncwg, nrepwg, nwritewg, ndcchunk, ngroups, groups_per_row;
+    uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word;
+    uint64_t raw_bytes, ustream_bytes, blk_entries, dca_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
+        dcsum_entries;
+} hjd_layout_info;
+int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int sync_overlap, int out_format, hjd_layout_info *out);
+
 #ifdef __cplusplus
 }
 #endif
