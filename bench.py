@@ -31,7 +31,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_PEAK_GINST = 1024 * 1.2   # wave-instructions/ns-free form: 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G wave-instr/s
+# fp32 VALU issue, G wave-instructions/s: nominal = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide's
+# figure); measured = v_mul_f32 at 8 waves per SIMD, independent accumulators, on this chip (tools/pk_rate.hip,
+# profiles/r02_pk_rate.txt: 4.44 cycles per wave-instruction per SIMD; v_pk_mul_f32 / v_pk_add_f32 4.8-5.0)
+VALU_PEAK_NOMINAL_GINST = 1024 * 2.4 / 2
+VALU_PEAK_MEASURED_GINST = 1024 * 2.4 / 4.44
 
 
 def host_cores():
@@ -294,33 +298,47 @@ def main():
         value = total_pixels * args.steps / dt / 1e6
         dom = max(stages_iso, key=lambda x: x[1]) if stages_iso else ("none", 0.0)
         ovl = dict(stages_ovl)
-        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair",
-                     "scan": "k_scan", "huff_write": "k_write", "dc_scan": "k_dcsum+k_dcapply", "idct_color": "k_idct_color",
-                     "boff_clear": "hipMemsetAsync", "reset": "hipMemsetAsync"}
-        achieved = launch_alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+        kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair_totals",
+                     "scan": "k_scan", "huff_write": "k_write", "dc_scan": "k_dcsum+k_dcapply", "idct_color": "k_idct_color"}
         images_per_launch = len(jpgs) // ns
-        traffic, valu = None, None
-        for fname, key in (("traffic.json", "hbm_bytes_per_launch"), ("sq_counters.json", "valu_insts_per_launch")):
+
+        def committed(fname):
+            """per-stage PMC summaries under profiles/ (collected by tools/gpu_profile.sh on the same launch shape)"""
             try:
-                ent = json.load(open(os.path.join(ROOT, "profiles", fname))).get(dom[0])
-                if ent and ent.get("images_per_launch") == images_per_launch and ent.get("width") == W and ent.get("height") == H:
-                    if fname == "traffic.json":
-                        traffic = ent[key]
-                    else:
-                        valu = ent[key]
+                d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                return {k: v for k, v in d.items()
+                        if v.get("images_per_launch") == images_per_launch and v.get("width") == W and v.get("height") == H}
             except Exception:
-                pass
+                return {}
+        tj, sj = committed("traffic.json"), committed("sq_counters.json")
+        per_kernel = {}
+        valu_step = 0
+        for name, ms in stages_iso:
+            ent = {"kernel": kernel_of.get(name, name), "ms_isolated": round(ms, 4), "ms_overlapped": round(ovl.get(name, 0.0), 4),
+                   "hbm_frac": round(launch_alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None,
+                   "traffic": tj.get(name, {}).get("hbm_bytes_per_launch")}
+            vi = sum(v.get("valu_insts_per_launch", 0) for k, v in sj.items() if k == name or (name == "unstuff" and k == "unstuff_count")
+                     or (name == "dc_scan" and k == "dc_sum"))
+            if vi:
+                ent["valu_insts"] = vi
+                ent["valu_frac_of_measured_peak"] = round(vi / (ms * 1e-3) / 1e9 / VALU_PEAK_MEASURED_GINST, 4)
+                valu_step += vi * ns
+            per_kernel[name] = ent
+        achieved = launch_alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
         roof = {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": per_kernel.get(dom[0], {}).get("traffic"),
                 "kernel_ms_isolated": round(dom[1], 4), "kernel_ms_overlapped": round(ovl.get(dom[0], 0.0), 4),
                 "algorithmic_bytes_per_launch": int(launch_alg_bytes), "images_per_launch": images_per_launch,
                 "launches_per_step": ns,
-                "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        if valu:  # second view of the same kernel: fp32 VALU issue (wave-instructions from the committed PMC summary)
-            ginst = valu / (dom[1] * 1e-3) / 1e9
-            roof["valu"] = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-                            "frac": round(ginst / VALU_PEAK_GINST, 4), "wave_insts_per_launch": valu}
+                "pipeline_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "per_kernel": per_kernel}
+        if valu_step:  # what actually bounds the path: fp32/int VALU issue (instruction counts from the committed PMC summary)
+            g = valu_step / (ms_step * 1e-3) / 1e9
+            roof["valu"] = {"bound": "valu", "achieved": round(g, 1), "peak": round(VALU_PEAK_MEASURED_GINST, 1),
+                            "peak_nominal": VALU_PEAK_NOMINAL_GINST, "unit": "G wave-instr/s",
+                            "frac": round(g / VALU_PEAK_MEASURED_GINST, 4), "frac_of_nominal": round(g / VALU_PEAK_NOMINAL_GINST, 4),
+                            "wave_insts_per_step": valu_step, "scope": "whole step, all kernels, overlapped streams"}
         out = {
             "metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)",
             "value": round(value, 1),

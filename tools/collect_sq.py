@@ -20,7 +20,7 @@ import glob
 import json
 import sys
 
-STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair", "k_write": "huff_write",
+STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair_first", "k_repair_totals": "huff_repair", "k_write": "huff_write",
             "k_unstuff_write": "unstuff", "k_unstuff_count": "unstuff_count", "k_dcapply": "dc_scan", "k_dcsum": "dc_sum",
             "k_scan": "scan", "k_gate": "repair_gate"}
 CLK = 2.4e9
