@@ -9,7 +9,7 @@ ARCH ?= gfx950
 # -ffp-contract=off is REQUIRED: the reference's fp32 IDCT/colour maths round after every operation
 # EXTRA: experiment switches, e.g. make lib EXTRA=-DHJD_COLOR_TRUNC=0
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-result $(EXTRA)
-SRCS = $(PKG)/csrc/hjd_unstuff.hip $(PKG)/csrc/hjd_entropy.hip $(PKG)/csrc/hjd_pixels.hip $(PKG)/host/hjd_api.cpp $(PKG)/host/hjd_host.cpp $(PKG)/host/openjpg_compat.cpp
+SRCS = $(PKG)/csrc/hjd_unstuff.hip $(PKG)/csrc/hjd_entropy.hip $(PKG)/csrc/hjd_pixels.hip $(PKG)/csrc/hjd_seq.hip $(PKG)/host/hjd_api.cpp $(PKG)/host/hjd_host.cpp $(PKG)/host/openjpg_compat.cpp
 HDRS = include/hjd.h $(PKG)/csrc/hjd_device.h $(PKG)/csrc/hjd_kernels.h $(PKG)/csrc/hjd_kutil.h $(PKG)/host/hjd_internal.h $(PKG)/host/openjpg_compat.h
 
 all: lib oracle tools

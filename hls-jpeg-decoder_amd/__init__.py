@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query",
 ]
 
 
@@ -52,7 +52,7 @@ class LayoutInfo(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("subseq_bits", ctypes.c_int), ("sync_launches", ctypes.c_int), ("streams", ctypes.c_int),
-                ("sync_overlap", ctypes.c_int), ("reserved", ctypes.c_int * 4)]
+                ("sync_overlap", ctypes.c_int), ("dirty_mode", ctypes.c_int), ("reserved", ctypes.c_int * 3)]
 
 
 _lib = None
@@ -128,6 +128,8 @@ def lib():
     L.hjd_batch_sync_stats.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
     L.hjd_batch_resync_count.restype = ctypes.c_int
     L.hjd_batch_resync_count.argtypes = [vp]
+    L.hjd_batch_sequential_count.restype = ctypes.c_int
+    L.hjd_batch_sequential_count.argtypes = [vp]
     L.hjd_decode_batch_host.restype = ctypes.c_int
     L.hjd_decode_batch_host.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), ctypes.c_int,
                                         ctypes.POINTER(vp), ctypes.POINTER(sz), ip]
@@ -164,8 +166,8 @@ def parse_header(jpg):
 class Decoder:
     """hjd_decoder: one per (process, device)."""
 
-    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0):
-        opt = Options(subseq_bits, sync_launches, streams, sync_overlap)
+    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0, dirty_mode=0):
+        opt = Options(subseq_bits, sync_launches, streams, sync_overlap, dirty_mode)
         self._h = lib().hjd_decoder_create(device, ctypes.byref(opt))
         if not self._h:
             raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))
@@ -327,6 +329,9 @@ class Batch:
 
     def resync_count(self):
         return lib().hjd_batch_resync_count(self._h)
+
+    def sequential_count(self):
+        return lib().hjd_batch_sequential_count(self._h)
 
     def info(self, i):
         w, h = ctypes.c_uint(), ctypes.c_uint()

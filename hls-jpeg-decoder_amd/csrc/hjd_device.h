@@ -50,6 +50,16 @@
 #define HJD_SEC_BITS (16 - HJD_LUT_BITS)
 #define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
 #define HJD_MAX_SEC 512
+// The same table in the canonical form the reference's matching rule is stated in ("is `code` one of the codes
+// of length k?", IsInHuffmanCodes, loadjpg.cpp:335-392) — for the sequential emulation kernel (hjd_seq.hip).
+struct HjdCanon {
+    uint16_t mincode[17]; // smallest code of each length
+    uint16_t count[17];   // codes of each length
+    uint16_t first[17];   // index into vals of the first code of each length
+    uint8_t vals[256];    // symbols in code order
+    uint8_t pad[2];
+};
+
 struct HjdTableSet {
     uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)
     uint32_t nsec;       // secondary tables in use
@@ -57,6 +67,7 @@ struct HjdTableSet {
     uint32_t pad;
     uint16_t lut[HJD_SLOTS][HJD_LUT_SIZE];
     uint16_t sec[HJD_MAX_SEC][1 << HJD_SEC_BITS];
+    HjdCanon canon[HJD_SLOTS]; // per slot (component*2 + isAC)
 };
 
 struct HjdImage {

@@ -47,4 +47,5 @@ int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s);
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);
+int hjd_launch_seq_decode(const HjdParams &P, const uint32_t *d_list, uint32_t n, hipStream_t s); // images listed by index
 int hjd_launch_color_table(uint8_t *d_out, hipStream_t s); // test hook: 3 << 24 bytes

@@ -1,0 +1,173 @@
+// hjd_seq.hip — the reference's entropy decoder, literally and sequentially (gfx950), for the restart
+// streams on which it leaves the clean-resync domain.
+//   k_seq_decode   ProcessHuffmanBlock + FillNBits with the reference's BYTE-CURSOR rules
+//                  (loadjpg.cpp:446-484, :499-863, :945-997, :1148-1182)
+//
+// The parallel path (hjd_entropy.hip) is valid where "jump to the marker at the end of an interval" equals
+// what the reference does.  Where it does not — the resync check fires on a block whose real bits are
+// still in the reservoir (:535-550), or between a DC code and its extra bits (:631-640), or a marker is
+// swallowed as data by the bit reader (:468-482) — the reference still produces defined bytes.  This kernel
+// reproduces them: ONE lane per image walks the stuffed scan exactly as the reference does (byte cursor,
+// 32-bit reservoir filled at most two bytes at a time, resync = cursor += 2 and reservoir cleared, DC
+// predictors never reset) and writes the same outputs as k_write + the DC scan: records, block entries,
+// predicted DC.  It is slow (one dependent chain per image) and only launched for images the parallel path
+// flagged DIRTY.  Like the reference (and the oracle) it reads zeros past the end of the scan: a desynchronised
+// decode may well finish its blocks there.  What the reference cannot decode either — no matching code (it loops forever,
+// :700-829), a zig-zag index past 63 (it writes outside DCT[], :780-806) — is flagged, not emulated.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hjd_device.h"
+#include "hjd_kernels.h"
+
+__constant__ uint8_t c_zz_to_slot_seq[64] = HJD_ZZ_TO_SLOT;
+
+struct SeqReader { // stHuffmanData::m_stream / stream_index / g_reservoir / g_nbits_in_reservoir (loadjpg.h:149-153)
+    const uint8_t *s;
+    uint32_t n, idx, res, nbits;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i < n ? s[i] : 0u; }
+    __device__ __forceinline__ void fill(uint32_t limit) // FillNBits, live branch loadjpg.cpp:468-482
+    {
+        for (int k = 0; k < 2; k++)
+            if (nbits < limit) {
+                const uint32_t c = at(idx);
+                idx++;
+                res <<= 8;
+                if (c == 0xFFu && at(idx) == 0x00u) idx++;
+                res |= c;
+                nbits += 8;
+            }
+    }
+    __device__ __forceinline__ void skip(uint32_t k) // loadjpg.cpp:607-609
+    {
+        fill(k);
+        nbits -= k;
+        res &= (1u << nbits) - 1u;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t k) // :647-652
+    {
+        fill(k);
+        const uint32_t v = res >> (nbits - k);
+        nbits -= k;
+        res &= (1u << nbits) - 1u;
+        return v;
+    }
+    __device__ __forceinline__ bool on_marker() const { return at(idx) == 0xFFu && at(idx + 1) != 0x00u; }
+    __device__ __forceinline__ void resync() // :544-546 / :634-636
+    {
+        idx += 2;
+        res = 0;
+        nbits = 0;
+    }
+};
+
+// IsInHuffmanCodes (loadjpg.cpp:335-392): is `code` a code of length k?  Canonical form of the table.
+__device__ __forceinline__ bool seq_match(const HjdCanon &t, uint32_t code, uint32_t k, uint32_t &value)
+{
+    const uint32_t c = t.count[k];
+    if (c == 0u || code < t.mincode[k] || code >= t.mincode[k] + c) return false;
+    value = t.vals[t.first[k] + (code - t.mincode[k])];
+    return true;
+}
+
+__device__ __forceinline__ int seq_extend(uint32_t v, uint32_t n) // DetermineSign, loadjpg.cpp:396-409
+{
+    return v < (1u << (n - 1u)) ? (int)v - (int)((1u << n) - 1u) : (int)v;
+}
+
+__global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, const uint32_t *__restrict__ list)
+{
+    if (threadIdx.x != 0) return;
+    const int ii = (int)list[blockIdx.x];
+    const HjdImage &im = P.img[ii];
+    const HjdTableSet &ts = P.tabs[im.tabset];
+    SeqReader r = {P.raw + im.raw_off, im.scan_len, 0u, 0u, 0u}; // loadjpg.cpp:1148-1149
+    uint32_t *rec = P.rec + im.rec_off;
+    uint4 *blk = P.blk + im.blk_off;
+    int16_t *dca = P.dca + im.blk_off;
+    int prev[3] = {0, 0, 0}; // :1159-1162, never reset afterwards
+    uint32_t nrec = 0, flags = 0;
+    const bool restart = im.restart != 0;
+
+    for (uint32_t b = 0; b < im.nblocks && !flags; b++) {
+        const uint32_t m = b % im.nb;
+        const uint32_t comp = m < im.nby ? 0u : m - im.nby + 1u; // DecodeMCU order, :945-997
+        const HjdCanon &hdc = ts.canon[comp * 2], &hac = ts.canon[comp * 2 + 1];
+        const uint32_t first = nrec;
+        uint32_t mlo = 0, mhi = 0, sym = 0;
+
+        if (restart && r.on_marker()) r.resync(); // block-start check, :535-550
+
+        bool found = false;
+        int dc = prev[comp];
+        for (uint32_t k = 1; k < 16; k++) { // :562: DC codes of 1..15 bits
+            r.fill(k);
+            if (seq_match(hdc, r.res >> (r.nbits - k), k, sym)) {
+                r.skip(k);
+                found = true;
+                if (sym != 0u) {
+                    if (restart && r.on_marker()) r.resync(); // between the code and its extra bits, :631-640
+                    const int data = (int)(int16_t)seq_extend(r.get(sym), sym);
+                    dc = (int)(int16_t)(data + prev[comp]); // :664
+                    prev[comp] = dc;
+                }
+                break;
+            }
+        }
+        if (!found) { // the reference prints and carries on with the AC loop on the same bits (:680-685): not emulated
+            flags |= HJD_FLAG_BAD_CODE;
+            break;
+        }
+
+        uint32_t nr = 1;
+        bool eob = false;
+        while (nr <= 63u && !eob) { // :700
+            bool hit = false;
+            for (uint32_t k = 1; k <= 16; k++) { // :713
+                r.fill(k);
+                if (seq_match(hac, r.res >> (r.nbits - k), k, sym)) {
+                    r.skip(k);
+                    hit = true;
+                    const uint32_t size = sym & 15u, run = sym >> 4; // :768-769
+                    if (size == 0u) {
+                        if (run == 0u) eob = true;      // :773
+                        else if (run == 15u) nr += 16u; // :774; other runs with size 0 are ignored
+                        else if (r.idx > im.scan_len + 4u) flags |= HJD_FLAG_BAD_CODE; // an ignored symbol decoded from the zeros
+                                                                                      // past the end: the reference repeats it forever
+                    } else {
+                        nr += run; // :778
+                        if (nr > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806)
+                            flags |= HJD_FLAG_OVERRUN;
+                            break;
+                        }
+                        const int data = (int)(int16_t)seq_extend(r.get(size), size);
+                        const uint32_t slot = c_zz_to_slot_seq[nr];
+                        if (nrec < im.rec_cap) rec[nrec] = ((uint32_t)data & 0xFFFFu) | (slot << 16) | ((b & 127u) << 22);
+                        else flags |= HJD_FLAG_OVERRUN;
+                        nrec++;
+                        nr++;
+                        if (slot < 32u) mlo |= 1u << slot;
+                        else mhi |= 1u << (slot - 32u);
+                    }
+                    break;
+                }
+            }
+            if (!hit) flags |= HJD_FLAG_BAD_CODE; // no code of 1..16 bits: the reference's loop makes no progress
+            if (flags) break;
+        }
+        blk[b] = make_uint4(first, 0u, mlo, mhi);
+        dca[b] = (int16_t)dc;
+    }
+    blk[im.nblocks] = make_uint4(min(nrec, im.rec_cap), 0u, 0u, 0u);
+    HjdImageState &st = P.st[ii];
+    st.flags = flags; // replaces the parallel path's verdict (DIRTY) for this image
+    st.total_blocks = flags ? 0u : im.nblocks;
+}
+
+int hjd_launch_seq_decode(const HjdParams &P, const uint32_t *d_list, uint32_t n, hipStream_t s)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_seq_decode, dim3(n), dim3(64), 0, s, P, d_list);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}

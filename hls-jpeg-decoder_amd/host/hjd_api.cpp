@@ -62,6 +62,7 @@ struct hjd_decoder {
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
+    int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
     // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
     // k+1's upload and chunk k-1's download run beside chunk k's kernels
     struct Slot {
@@ -98,6 +99,7 @@ struct hjd_batch {
     std::vector<hipEvent_t> join_ev;
     hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
+    int dirty_decodes = 0;           // images decoded by the sequential emulation kernel since prepare
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
@@ -189,6 +191,18 @@ static bool build_tabset(HjdTableSet &ts, const hjd_jpeg_data &j)
         specs[(c - 1) * 2 + 0] = &j.htdc[j.dc_table_index[c]];
         specs[(c - 1) * 2 + 1] = &j.htac[j.ac_table_index[c]];
     }
+    for (int sl = 0; sl < HJD_SLOTS; sl++) { // canonical form for the sequential emulation kernel (GenHuffCodes, openjpg.cpp:48-66)
+        HjdCanon &c = ts.canon[sl];
+        unsigned code = 0, idx = 0;
+        for (int k = 1; k <= 16; k++) {
+            c.mincode[k] = (uint16_t)code;
+            c.count[k] = specs[sl]->bits[k];
+            c.first[k] = (uint16_t)idx;
+            code = (code + specs[sl]->bits[k]) << 1;
+            idx += specs[sl]->bits[k];
+        }
+        memcpy(c.vals, specs[sl]->vals, 256);
+    }
     for (int sl = 0; sl < HJD_SLOTS; sl++) {
         int ti = -1;
         for (int q = 0; q < sl; q++)
@@ -253,6 +267,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         }
         if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
         if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
+        d->dirty_mode = opt->dirty_mode ? 1 : 0;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
@@ -366,6 +381,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->nchunks = b->nsub = b->nsyncwg = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
+    b->dirty_decodes = 0;
     DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     const uint32_t S = d->subseq_bits;
@@ -463,7 +479,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             // bits takes at least 2 bits of scan: a 1-bit code for (run 0, size 1) plus the value bit), plus
             // the rounding of every subsequence's run to a whole burst
             const uint64_t by_blocks = (uint64_t)im.nblocks * 63, by_bits = (uint64_t)im.scan_len * 8 / 2;
-            const uint64_t cap = (by_blocks < by_bits ? by_blocks : by_bits) + (uint64_t)HJD_REC_RUN * im.nsub_cap + 64;
+            // With DRI the reference may leave the marker grid and finish its blocks on the zeros past the end of the
+            // scan (sequential emulation, hjd_seq.hip): only the per-block bound holds there.
+            const uint64_t bound = im.restart ? by_blocks : (by_blocks < by_bits ? by_blocks : by_bits);
+            const uint64_t cap = bound + (uint64_t)HJD_REC_RUN * im.nsub_cap + 64;
             im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~(uint32_t)(HJD_REC_RUN - 1);
         }
         im.rec_off = rec_cur;
@@ -995,6 +1014,35 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             if (rc) return rc;
         }
     }
+    if (b->nimg && overall == HJD_OK && b->dec->dirty_mode == 0) {
+        // Restart streams on which the reference leaves the clean-resync domain (and nothing else is wrong): decode
+        // them again the way the reference does, one sequential lane per image (k_seq_decode), then the back end.
+        std::vector<uint32_t> dirty;
+        for (int k = 0; k < b->nimg; k++) {
+            const uint32_t f = b->state[k].flags;
+            if (f & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) dirty.push_back((uint32_t)k); // whatever else the parallel path flagged
+                                                                                          // after leaving the domain means nothing
+        }
+        if (!dirty.empty()) {
+            uint32_t *d_list = nullptr;
+            HIPCHK(hipMalloc(&d_list, sizeof(uint32_t) * dirty.size()));
+            int rc = HJD_OK;
+            if (hipMemcpyAsync(d_list, dirty.data(), sizeof(uint32_t) * dirty.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = HJD_ERR_INTERNAL;
+            if (rc == HJD_OK && hjd_launch_seq_decode(b->P, d_list, (uint32_t)dirty.size(), s)) rc = HJD_ERR_INTERNAL;
+            for (size_t q = 0; q < dirty.size() && rc == HJD_OK; q++) {
+                HjdParams P = b->P;
+                P.off_group = b->img[dirty[q]].group0;
+                if (hjd_launch_idct_color(P, b->img[dirty[q]].ngroups, s)) rc = HJD_ERR_INTERNAL;
+            }
+            if (rc == HJD_OK && hipStreamSynchronize(s) != hipSuccess) rc = HJD_ERR_INTERNAL;
+            if (rc == HJD_OK &&
+                hipMemcpy(b->state.data(), b->d_st, sizeof(HjdImageState) * b->nimg, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = HJD_ERR_INTERNAL;
+            (void)hipFree(d_list);
+            if (rc != HJD_OK) return rc;
+            b->dirty_decodes += (int)dirty.size();
+        }
+    }
     for (int i = 0; i < b->n; i++) {
         int st = b->parse_status[i];
         const int di = b->dev_index[i];
@@ -1092,6 +1140,7 @@ extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)
 }
 
 extern "C" int hjd_batch_resync_count(const hjd_batch *b) { return b ? b->resyncs : -1; }
+extern "C" int hjd_batch_sequential_count(const hjd_batch *b) { return b ? b->dirty_decodes : -1; }
 
 extern "C" int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *alg, uint64_t *scan)
 {
@@ -1138,10 +1187,11 @@ static int pipe_retire(hjd_decoder *d, hjd_decoder::Slot &sl, uint8_t *const *ou
     sl.busy = false;
     HIPCHK(hipEventSynchronize(sl.down_done));
     std::vector<int> st(sl.count, 0);
-    const int before = sl.b->resyncs;
+    const int before = sl.b->resyncs + sl.b->dirty_decodes;
     int rc = hjd_batch_finish(sl.b, d->s_run, st.data());
     if (rc != HJD_OK) return rc;
-    const bool redo = sl.b->resyncs != before; // outputs changed after the download was enqueued (host re-synchronisation)
+    // outputs changed after the download was enqueued (host re-synchronisation, sequential emulation of dirty restart streams)
+    const bool redo = sl.b->resyncs + sl.b->dirty_decodes != before;
     for (int k = 0; k < sl.count; k++) {
         const int i = sl.first + k;
         if (status) status[i] = st[k];

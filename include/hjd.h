@@ -29,7 +29,7 @@ typedef enum hjd_status {
     HJD_ERR_NOT_JPEG = 1,       /* openjpg.cpp:481-486 / :383-386: no SOI, or a marker without 0xFF */
     HJD_ERR_UNSUPPORTED = 2,    /* valid JPEG outside the reference's domain (progressive, grey, 16-bit DQT, ...) */
     HJD_ERR_CORRUPT = 3,        /* truncated segment, invalid Huffman code or coefficient overrun in the scan */
-    HJD_ERR_DIRTY_RESTART = 4,  /* restart stream outside the clean-resync domain */
+    HJD_ERR_DIRTY_RESTART = 4,  /* restart stream outside the clean-resync domain, with hjd_options.dirty_mode = 1 */
     HJD_ERR_NO_DEVICE = 5,      /* no usable HIP device / kernel image: the product path has no CPU fallback */
     HJD_ERR_ARG = 6,            /* NULL pointer, size too small, bad enum */
     HJD_ERR_IO = 7,             /* file open/read/write failed */
@@ -115,7 +115,10 @@ typedef struct hjd_options {
     int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
                           * 0 = default (8192 bits' worth), -1 = none, 1..48 = that many.  Too little warm-up is
                           * never wrong, only slower: hjd_batch_finish then re-synchronises from the host. */
-    int reserved[4];
+    int dirty_mode;      /* restart streams on which the reference leaves the clean-resync domain:
+                          * 0 = decoded the way the reference decodes them, by a sequential emulation kernel (slow, exact);
+                          * 1 = refused with HJD_ERR_DIRTY_RESTART */
+    int reserved[3];
 } hjd_options;
 
 hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);
@@ -165,6 +168,9 @@ int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
 /* Number of host-driven re-synchronisation rounds hjd_batch_finish had to run since prepare
  * (0 in normal operation: the in-stream repair launch already settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);
+/* Number of images of this batch that hjd_batch_finish decoded with the sequential emulation of the reference
+ * (restart streams outside the clean-resync domain) since prepare / reset. */
+int hjd_batch_sequential_count(const hjd_batch *b);
 
 /* A batch object that can be prepared again and again in place: slabs and pinned staging are re-allocated only
  * when new contents need more than they hold.  hjd_batch_reset = the work of hjd_batch_prepare on an existing
