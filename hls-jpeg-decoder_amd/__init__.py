@@ -22,7 +22,7 @@ MAX_STAGES = 16
 # every symbol include/hjd.h declares
 EXPORTS = [
     "hjd_status_string", "hjd_last_status", "hjd_convert_jpg_file", "hjd_decode_jpg_file_data", "hjd_free",
-    "hjd_parse_header", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
+    "hjd_parse_header", "hjd_parse_header_ex", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
     "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query",
@@ -52,7 +52,7 @@ class LayoutInfo(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("subseq_bits", ctypes.c_int), ("sync_launches", ctypes.c_int), ("streams", ctypes.c_int),
-                ("sync_overlap", ctypes.c_int), ("dirty_mode", ctypes.c_int), ("reserved", ctypes.c_int * 3)]
+                ("sync_overlap", ctypes.c_int), ("dirty_mode", ctypes.c_int), ("conformant", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
 
 
 _lib = None
@@ -85,6 +85,8 @@ def lib():
     L.hjd_free.argtypes = [vp]
     L.hjd_parse_header.restype = ctypes.c_int
     L.hjd_parse_header.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(JpegData)]
+    L.hjd_parse_header_ex.restype = ctypes.c_int
+    L.hjd_parse_header_ex.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(JpegData), ctypes.c_int]
     L.hjd_jpeg_decode_hw.restype = ctypes.c_int
     L.hjd_jpeg_decode_hw.argtypes = [ctypes.POINTER(JpegData), ctypes.c_uint, ctypes.c_uint, ctypes.c_ubyte,
                                      ctypes.c_ubyte, vp]
@@ -166,8 +168,8 @@ def parse_header(jpg):
 class Decoder:
     """hjd_decoder: one per (process, device)."""
 
-    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0, dirty_mode=0):
-        opt = Options(subseq_bits, sync_launches, streams, sync_overlap, dirty_mode)
+    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0, dirty_mode=0, conformant=0):
+        opt = Options(subseq_bits, sync_launches, streams, sync_overlap, dirty_mode, conformant)
         self._h = lib().hjd_decoder_create(device, ctypes.byref(opt))
         if not self._h:
             raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))

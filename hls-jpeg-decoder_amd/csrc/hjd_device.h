@@ -102,6 +102,8 @@ struct HjdImage {
     uint32_t mark_cap;      // entries reserved
     uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
     uint32_t rec_cap;       // records reserved
+    uint32_t conformant;    // hjd_options.conformant: DC reset at RSTn, true-cosine rounding IDCT, rounding colour
+    uint32_t pad1;
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)

@@ -114,6 +114,7 @@ struct RestartCtx {
     uint32_t mk;          // index of the next marker (first position > p)
     uint32_t ri_blocks;   // blocks per interval, 0 = no intervals expected
     uint32_t left;        // WRITE: blocks left in the current interval
+    uint32_t conf;        // conformant mode (hjd_options.conformant): the standard's interval rule instead of the reference's
 };
 
 // WRITE: the lane's records waiting for their 16-byte store (shift register: r3 is the newest), and
@@ -193,7 +194,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 W.bfirst = nrec;
                 W.bdc = (uint32_t)(int)(int16_t)val;
                 // the reference looks for a marker again between the DC code and its extra bits
-                if (RESTART && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
+                if (RESTART && !rc.conf && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
                 const uint32_t slot = W.slot_of[zw & 63u];
@@ -234,7 +235,27 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         const uint32_t tot = len + s;
         p += tot;
         rd.advance(tot);
-        if (RESTART) {
+        if (RESTART && rc.conf) {
+            // Conformant mode (never the default): ITU T.81 B.2.4.1 / F.1.2.3 — an interval ends where nothing but
+            // padding (1-bits up to the byte boundary) separates the end of a block from the marker.  Decidable
+            // from the bits alone, so the speculative and the final pass apply the same rule.
+            bool jump = p > mnext;
+            if (blk_end && !jump) {
+                const uint32_t d = mnext - p;
+                if (d < 8u) jump = d == 0u || (rd.window() >> (32u - d)) == (1u << d) - 1u;
+            }
+            if (jump) {
+                p = mnext;
+                z = 0u;
+                m = 0u;
+                pair = tabY;
+                tb = pair & 0xFFFFu;
+                rc.mk++;
+                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                if (p >= end) break;
+                rd.init(rowp, p - row_bit0);
+            }
+        } else if (RESTART) {
             if (WRITE && blk_end) rc.left--;
             if ((blk_end && p + 8u > mnext) || p > mnext) {
                 if (WRITE && nblk < W.nblocks) {
@@ -282,7 +303,7 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
     const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, E.total_bits);
-    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0};
+    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
     if (im.restart && active) {
         rc.nmark = E.nmark;
         uint32_t lo = 0, hi = rc.nmark; // first marker past the start of this row

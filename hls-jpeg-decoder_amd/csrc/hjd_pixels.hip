@@ -35,6 +35,17 @@ __constant__ float c_cos[64] = {
     0x1p+0f, -0x1.a9581p-1f, 0x1.856b06p-2f, 0x1.9756cp-3f, -0x1.6be866p-1f, 0x1.f6cc3cp-1f, -0x1.d77dbp-1f, 0x1.1895aep-1f,
     0x1p+0f, -0x1.f6032cp-1f, 0x1.d8706ep-1f, -0x1.a86f2p-1f, 0x1.67dec4p-1f, -0x1.19442cp-1f, 0x1.7f609p-2f, -0x1.7a87f6p-3f};
 
+// Conformant mode only (hjd_options.conformant, SURVEY §8f N4 — never the default): COS[x][u] = cos((2x+1) u pi / 16).
+__constant__ float c_cos_true[64] = {
+    1.0f, 0.98078528f, 0.92387953f, 0.83146961f, 0.70710678f, 0.55557023f, 0.38268343f, 0.19509032f,
+    1.0f, 0.83146961f, 0.38268343f, -0.19509032f, -0.70710678f, -0.98078528f, -0.92387953f, -0.55557023f,
+    1.0f, 0.55557023f, -0.38268343f, -0.98078528f, -0.70710678f, 0.19509032f, 0.92387953f, 0.83146961f,
+    1.0f, 0.19509032f, -0.92387953f, -0.55557023f, 0.70710678f, 0.83146961f, -0.38268343f, -0.98078528f,
+    1.0f, -0.19509032f, -0.92387953f, 0.55557023f, 0.70710678f, -0.83146961f, -0.38268343f, 0.98078528f,
+    1.0f, -0.55557023f, -0.38268343f, 0.98078528f, -0.70710678f, -0.19509032f, 0.92387953f, -0.83146961f,
+    1.0f, -0.83146961f, 0.38268343f, 0.19509032f, -0.70710678f, 0.98078528f, -0.92387953f, 0.55557023f,
+    1.0f, -0.98078528f, 0.92387953f, -0.83146961f, 0.70710678f, -0.55557023f, 0.38268343f, -0.19509032f};
+
 #define MAXGB (HJD_GROUP_MCUS * 6) // blocks per workgroup
 
 // ---- colour ------------------------------------------------------------------------------------
@@ -52,26 +63,28 @@ struct ChromaTerms {
     float a, b, c, d; // 1.402 cr', 0.34414 cb', 0.71414 cr', 1.772 cb'   (x' = x - 128)
 };
 
+template <bool CONF = false>
 __device__ __forceinline__ ChromaTerms chroma_terms(uint32_t cb, uint32_t cr)
 {
     const float fcb = (float)cb - 128.0f, fcr = (float)cr - 128.0f; // == (float)(c - 128) exactly
     ChromaTerms t;
     t.a = 1.402f * fcr;
-    t.b = 0.34414f * fcb;
-    t.c = 0.71414f * fcr;
+    t.b = (CONF ? 0.344136f : 0.34414f) * fcb; // conformant mode: the JFIF constants
+    t.c = (CONF ? 0.714136f : 0.71414f) * fcr;
     t.d = 1.772f * fcb;
     return t;
 }
 
 // byte `sel` of `acc` <- clamp((int)x, 0, 255)
+template <bool CONF = false>
 __device__ __forceinline__ uint32_t put_u8(float x, uint32_t sel, uint32_t acc)
 {
-    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(x), sel, acc);
+    return __builtin_amdgcn_cvt_pk_u8_f32(CONF ? __builtin_floorf(x + 0.5f) : __builtin_truncf(x), sel, acc); // conformant: round
 }
 
 // Four pixels -> the 12 bytes c0,g,c2 x 4 (c0 = R and c2 = B for the m_rgb layout, swapped for BMP).
 // y4 = four luma bytes; t0..t3 = chroma terms of the four pixels (4:2:x callers pass each pair twice).
-template <bool bgr>
+template <bool bgr, bool CONF = false>
 __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const ChromaTerms &t1, const ChromaTerms &t2,
                                       const ChromaTerms &t3, uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
@@ -84,16 +97,16 @@ __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const 
     const float f1 = bgr ? b1 : r1, l1 = bgr ? r1 : b1;
     const float f2 = bgr ? b2 : r2, l2 = bgr ? r2 : b2;
     const float f3 = bgr ? b3 : r3, l3 = bgr ? r3 : b3;
-    d0 = put_u8(f1, 3, put_u8(l0, 2, put_u8(g0, 1, put_u8(f0, 0, 0u))));
-    d1 = put_u8(g2, 3, put_u8(f2, 2, put_u8(l1, 1, put_u8(g1, 0, 0u))));
-    d2 = put_u8(l3, 3, put_u8(g3, 2, put_u8(f3, 1, put_u8(l2, 0, 0u))));
+    d0 = put_u8<CONF>(f1, 3, put_u8<CONF>(l0, 2, put_u8<CONF>(g0, 1, put_u8<CONF>(f0, 0, 0u))));
+    d1 = put_u8<CONF>(g2, 3, put_u8<CONF>(f2, 2, put_u8<CONF>(l1, 1, put_u8<CONF>(g1, 0, 0u))));
+    d2 = put_u8<CONF>(l3, 3, put_u8<CONF>(g3, 2, put_u8<CONF>(f3, 1, put_u8<CONF>(l2, 0, 0u))));
 }
 
 // Phase 3 of k_idct_color: nearest-neighbour chroma (loadjpg.cpp:911-912), colour, clip at the image edge
 // (:906-909), then either the m_rgb layout or the WriteBMP24 layout (openjpg.cpp:555-568).  A thread owns one
 // 4-pixel column of the group for good and walks chroma rows; everything that depends on the column only is
 // computed once, and the chroma products once per chroma sample row (they serve vf luma rows).
-template <bool BMP>
+template <bool BMP, bool CONF>
 __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
                                             uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
 {
@@ -117,17 +130,17 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
             if (hf == 2) { // pixels 0,1 and 2,3 share a chroma sample (cx = x/2)
                 const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb0[cy * 8 + (xin >> 1)]);
                 const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr0[cy * 8 + (xin >> 1)]);
-                t0 = t1 = chroma_terms(cb2 & 0xFF, cr2 & 0xFF);
-                t2 = t3 = chroma_terms(cb2 >> 8, cr2 >> 8);
+                t0 = t1 = chroma_terms<CONF>(cb2 & 0xFF, cr2 & 0xFF);
+                t2 = t3 = chroma_terms<CONF>(cb2 >> 8, cr2 >> 8);
             } else if (hf == 4) {
-                t0 = t1 = t2 = t3 = chroma_terms(pcb0[cy * 8 + (xin >> 2)], pcr0[cy * 8 + (xin >> 2)]);
+                t0 = t1 = t2 = t3 = chroma_terms<CONF>(pcb0[cy * 8 + (xin >> 2)], pcr0[cy * 8 + (xin >> 2)]);
             } else {
                 const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb0[cy * 8 + xin]);
                 const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr0[cy * 8 + xin]);
-                t0 = chroma_terms(cb4 & 0xFF, cr4 & 0xFF);
-                t1 = chroma_terms((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF);
-                t2 = chroma_terms((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF);
-                t3 = chroma_terms(cb4 >> 24, cr4 >> 24);
+                t0 = chroma_terms<CONF>(cb4 & 0xFF, cr4 & 0xFF);
+                t1 = chroma_terms<CONF>((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF);
+                t2 = chroma_terms<CONF>((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF);
+                t3 = chroma_terms<CONF>(cb4 >> 24, cr4 >> 24);
             }
             for (uint32_t dy = 0; dy < vf; dy++) {
                 const uint32_t row = (cy << lvf) + dy;
@@ -135,7 +148,7 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
                 if (gy >= H) break; // loadjpg.cpp:908
                 const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[ycol + ((row >> 3) << lhf)][(row & 7) * 8 + ybyte]);
                 uint32_t d0, d1, d2;
-                rgb12<BMP>(ypix, t0, t1, t2, t3, d0, d1, d2);
+                rgb12<BMP, CONF>(ypix, t0, t1, t2, t3, d0, d1, d2);
                 uint8_t *dst = BMP ? out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3 : out + (size_t)gy * stride + (size_t)gxp * 3;
                 if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
                     struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
@@ -199,11 +212,12 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     int dc = 0;
     if (tid <= KB) be = P.blk[gm.y + tid];
     if (tid < KB) dc = P.dca[gm.y + tid];
+    const bool conf = im.conformant != 0;
     if (tid < 64) {
-        s_cos[tid] = c_cos[(tid & 7) * 8 + (tid >> 3)];
+        s_cos[tid] = conf ? c_cos_true[(tid & 7) * 8 + (tid >> 3)] : c_cos[(tid & 7) * 8 + (tid >> 3)];
         // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
         const uint32_t u = tid >> 3, v = tid & 7;
-        s_kk[tid] = (u == 0) ? (v == 0 ? 0x1.fffffep-2f : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
+        s_kk[tid] = (u == 0) ? (v == 0 ? (conf ? 0.5f : 0x1.fffffep-2f) : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
     }
     if (tid < 48) reinterpret_cast<uint32_t *>(&s_qt[0][0])[tid] = reinterpret_cast<const uint32_t *>(&im.qt[0][0])[tid];
     if (tid <= KB) {
@@ -221,6 +235,13 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
     __syncthreads();
     if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0 (DequantizeBlock, loadjpg.cpp:144-152: int16 wrap)
+        if (conf && im.ri_blocks) {
+            // conformant mode: predictors restart with every interval = the running sum minus its value at the
+            // end of the previous interval (the reference, and the default mode, carry it across: loadjpg.cpp:1159-1162)
+            const uint32_t ri = im.ri_blocks / nb, mcu = (uint32_t)(gm.y - im.blk_off + tid) / nb;
+            const uint32_t s0 = mcu - mcu % ri;
+            if (s0) dc = (int)(int16_t)(dc - (int)P.dca[im.blk_off + (size_t)(s0 - 1u) * nb + (mycomp == 0 ? nby - 1u : nby + mycomp - 1u)]);
+        }
         const int16_t nat = (int16_t)(dc * (int)s_qt[mycomp][0]);
         s_coef[tid][0] = nat;
         if (nat != 0) atomicOr(&s_mask[tid][0], 1u);
@@ -301,7 +322,14 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
                 acc1[y] = acc1[y] * 0.25f;
                 big = fmaxf(big, fmaxf(fabsf(acc0[y]), fabsf(acc1[y])));
             }
-            if (big < 32000.0f) {
+            if (conf) { // conformant mode: round to nearest
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const uint32_t pp = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(acc1[y] + 128.5f), 1,
+                                        __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(acc0[y] + 128.5f), 0, 0u));
+                    *reinterpret_cast<uint16_t *>(&s_pix[blk][y * 8 + x0]) = (uint16_t)pp;
+                }
+            } else if (big < 32000.0f) {
 #pragma unroll
                 for (int y = 0; y < 8; y++) {
                     const uint32_t pp = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(acc1[y]) + 128.0f, 1,
@@ -322,8 +350,11 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __syncthreads();
 
     // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932) + output layout
-    if (im.out_format == 1) color_store<true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
-    else color_store<false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    if (conf) { // conformant mode (opt-in): rounding colour stage
+        if (im.out_format == 1) color_store<true, true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+        else color_store<false, true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    } else if (im.out_format == 1) color_store<true, false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    else color_store<false, false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
 }
 
 // Test hook: the colour stage, alone, over every (Y, Cb, Cr) triple.  Output: 3 bytes
@@ -333,8 +364,8 @@ __global__ __launch_bounds__(256) void k_color_table(uint8_t *out)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x; // (Y, Cb, quarter of Cr): four triples with consecutive Cr
     const uint32_t y = t >> 14, cb = (t >> 6) & 0xFF, cr0 = (t & 63u) * 4u;
     uint32_t d0, d1, d2;
-    rgb12<false>(y * 0x01010101u, chroma_terms(cb, cr0), chroma_terms(cb, cr0 + 1), chroma_terms(cb, cr0 + 2), chroma_terms(cb, cr0 + 3),
-                 d0, d1, d2);
+    rgb12<false, false>(y * 0x01010101u, chroma_terms<false>(cb, cr0), chroma_terms<false>(cb, cr0 + 1), chroma_terms<false>(cb, cr0 + 2),
+                        chroma_terms<false>(cb, cr0 + 3), d0, d1, d2);
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)((y << 16) | (cb << 8) | cr0) * 3u);
     dst[0] = d0;
     dst[1] = d1;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
             // anything but RSTn between the intervals: the reference would take it for a resync point too,
             // with results no standard stream defines (what follows the last interval — EOI, padding —
             // is never looked at again)
-            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7)) atomicOr(&P.st[ii].flags, HJD_FLAG_BAD_MARKER);
+            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7) && !im.conformant) atomicOr(&P.st[ii].flags, HJD_FLAG_BAD_MARKER);
             mk++;
         }
         if (mask & (1u << j)) {

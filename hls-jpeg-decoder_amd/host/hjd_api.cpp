@@ -63,6 +63,7 @@ struct hjd_decoder {
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
+    int conformant = 0;        // hjd_options.conformant: opt-in, outside the parity contract
     // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
     // k+1's upload and chunk k-1's download run beside chunk k's kernels
     struct Slot {
@@ -268,6 +269,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
         if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
         d->dirty_mode = opt->dirty_mode ? 1 : 0;
+        d->conformant = opt->conformant ? 1 : 0;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
@@ -396,7 +398,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         if (b->parse_status[i] != HJD_OK) continue;
         const hjd_jpeg_data &j = parsed[i];
         {   // the same checks for parsed headers and for caller-filled structs (hjd_jpeg_decode_hw)
-            const int vst = hjd_validate_jpeg_data(&j);
+            const int vst = hjd_validate_jpeg_data(&j, d->conformant ? HJD_PARSE_CONFORMANT : 0);
             if (vst != HJD_OK) {
                 b->parse_status[i] = vst;
                 continue;
@@ -452,6 +454,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->ngroups += im.ngroups;
         im.out_format = (uint32_t)b->out_format;
         im.restart = j.restart_interval > 0 ? 1u : 0u; // the reference only tests "> 0" (loadjpg.cpp:535)
+        im.conformant = d->conformant ? 1u : 0u;
         im.ri_blocks = im.restart ? j.restart_mcus * im.nb : 0u;
         im.mark_off = b->nmarks;
         im.mark_cap = im.restart ? (j.restart_mcus ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus : 0u) + 8u : 0u;
@@ -491,7 +494,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // stored by slot u*8+v (where DeZigZag + TransformArray put zig-zag entry k, loadjpg.cpp:156-180)
         for (int k = 0; k < 64; k++) {
             im.qt[0][kZzToSlot[k]] = j.qtable[1][k];
-            im.qt[1][kZzToSlot[k]] = j.qtable[3][k];
+            im.qt[1][kZzToSlot[k]] = d->conformant ? j.qtable[2][k] : j.qtable[3][k]; // conformant mode: Cb's own table
             im.qt[2][kZzToSlot[k]] = j.qtable[3][k];
         }
         b->dev_index[i] = (int)b->img.size();
@@ -795,7 +798,8 @@ extern "C" int hjd_batch_reset(hjd_batch *b, int n, const uint8_t *const *jpg, c
     if (!b || n < 0 || (n && (!jpg || !jpg_len)) || (out_format != HJD_OUT_RGB && out_format != HJD_OUT_BMP)) return HJD_ERR_ARG;
     std::vector<hjd_jpeg_data> parsed(n);
     std::vector<int> pst(n);
-    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]) : HJD_ERR_ARG;
+    const int pf = b->dec->conformant ? HJD_PARSE_CONFORMANT : 0;
+    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG;
     return batch_reset_parsed(b, n, parsed, pst, out_format, status, (hipStream_t)hip_stream, false);
 }
 
@@ -808,7 +812,8 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
     }
     std::vector<hjd_jpeg_data> parsed(n);
     std::vector<int> pst(n);
-    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header(jpg[i], jpg_len[i], &parsed[i]) : HJD_ERR_ARG;
+    const int pf = d->conformant ? HJD_PARSE_CONFORMANT : 0;
+    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG;
     return batch_from_parsed(d, n, parsed, pst, out_format, status);
 }
 
@@ -1337,7 +1342,7 @@ extern "C" int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int heigh
         !(vFactor == 1 || vFactor == 2 || vFactor == 4) || hFactor * vFactor > 4)
         return HJD_ERR_UNSUPPORTED; // hFactor = 0 is a SIGFPE in the reference (loadjpg.cpp:1153)
     {   // a caller-filled struct gets the checks hjd_parse_header applies, before anything is built from it
-        const int vst = hjd_validate_jpeg_data(&j);
+        const int vst = hjd_validate_jpeg_data(&j, 0);
         if (vst != HJD_OK) {
             hjd_set_last_status(vst);
             return vst;

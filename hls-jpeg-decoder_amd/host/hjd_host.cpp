@@ -35,7 +35,7 @@ extern "C" const char *hjd_status_string(int s)
 static inline unsigned be16(const uint8_t *p) { return ((unsigned)p[0] << 8) | p[1]; }
 
 // One DHT payload (bits[1..16], vals[]) as GenHuffCodes / BuildHuffmanTable would take it (openjpg.cpp:48-98).
-int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc)
+int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc, int flags)
 {
     if (!h->defined) return HJD_ERR_UNSUPPORTED;
     unsigned total = 0, code = 0;
@@ -47,14 +47,14 @@ int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc)
     }
     if (total > 255) return HJD_ERR_UNSUPPORTED; // uint8_t scan index never terminates (loadjpg.cpp:350-355)
     if (is_dc) {
-        if (h->bits[16]) return HJD_ERR_UNSUPPORTED; // DC search stops at 15 bits (loadjpg.cpp:562)
+        if (h->bits[16] && !(flags & HJD_PARSE_CONFORMANT)) return HJD_ERR_UNSUPPORTED; // DC search stops at 15 bits (loadjpg.cpp:562)
         for (unsigned k = 0; k < total; k++)
             if (h->vals[k] > 15) return HJD_ERR_UNSUPPORTED; // reader holds at most 2 new bytes (:468-482)
     }
     return HJD_OK;
 }
 
-int hjd_validate_jpeg_data(const hjd_jpeg_data *j)
+int hjd_validate_jpeg_data(const hjd_jpeg_data *j, int flags)
 {
     if (!j || !j->stream) return HJD_ERR_ARG;
     if (j->stream_len == 0) return HJD_ERR_CORRUPT;
@@ -64,9 +64,9 @@ int hjd_validate_jpeg_data(const hjd_jpeg_data *j)
     if (!(hf == 1 || hf == 2 || hf == 4) || !(vf == 1 || vf == 2 || vf == 4) || hf * vf > 4) return HJD_ERR_UNSUPPORTED;
     for (int c = 1; c <= 3; c++) {
         if (j->dc_table_index[c] > 3 || j->ac_table_index[c] > 3) return HJD_ERR_ARG;
-        int st = hjd_validate_huff_spec(&j->htdc[j->dc_table_index[c]], 1);
+        int st = hjd_validate_huff_spec(&j->htdc[j->dc_table_index[c]], 1, flags);
         if (st != HJD_OK) return st;
-        st = hjd_validate_huff_spec(&j->htac[j->ac_table_index[c]], 0);
+        st = hjd_validate_huff_spec(&j->htac[j->ac_table_index[c]], 0, flags);
         if (st != HJD_OK) return st;
     }
     return HJD_OK;
@@ -75,7 +75,9 @@ int hjd_validate_jpeg_data(const hjd_jpeg_data *j)
 // Header walk with the observable behaviour of JpegParseHeader/ParseJFIF (openjpg.cpp:371-496) on
 // the inputs the reference decodes correctly; everything it would mis-handle (SURVEY.md App. A.2,
 // App. E) is rejected with a status instead.
-extern "C" int hjd_parse_header(const uint8_t *buf, size_t n, hjd_jpeg_data *o)
+extern "C" int hjd_parse_header(const uint8_t *buf, size_t n, hjd_jpeg_data *o) { return hjd_parse_header_ex(buf, n, o, 0); }
+
+extern "C" int hjd_parse_header_ex(const uint8_t *buf, size_t n, hjd_jpeg_data *o, int flags)
 {
     if (!buf || !o) return HJD_ERR_ARG;
     memset(o, 0, sizeof(*o));
@@ -157,7 +159,7 @@ extern "C" int hjd_parse_header(const uint8_t *buf, size_t n, hjd_jpeg_data *o)
                 memset(h->vals, 0, sizeof(h->vals));
                 memcpy(h->vals, seg + q + 17, total);
                 h->defined = 1;
-                const int vst = hjd_validate_huff_spec(h, !(tc_th & 0xF0));
+                const int vst = hjd_validate_huff_spec(h, !(tc_th & 0xF0), flags);
                 if (vst != HJD_OK) {
                     h->defined = 0;
                     return vst;

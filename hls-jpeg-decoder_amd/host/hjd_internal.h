@@ -12,7 +12,8 @@ void hjd_set_last_status(int s);
 // caller of hjd_jpeg_decode_hw: table selectors in range and defined, DHT payloads that describe a
 // prefix code (sum of counts <= 255, no length over-subscribed), DC symbols <= 15 and no 16-bit DC
 // code (loadjpg.cpp:562), sampling factors the MCU loop supports, a non-empty scan.
-int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc);
-int hjd_validate_jpeg_data(const hjd_jpeg_data *j);
+// flags: HJD_PARSE_CONFORMANT admits what only the reference cannot take (16-bit DC codes)
+int hjd_validate_huff_spec(const hjd_huff_spec *h, int is_dc, int flags);
+int hjd_validate_jpeg_data(const hjd_jpeg_data *j, int flags);
 bool hjd_read_file(const char *path, std::vector<uint8_t> &out);
 bool hjd_write_file(const char *path, const uint8_t *data, size_t n);

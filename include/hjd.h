@@ -91,6 +91,10 @@ typedef struct hjd_jpeg_data {
 /* Host header walk.  Replaces JpegParseHeader / ParseJFIF (openjpg.cpp:371-496).
  * Fills `out`; out->stream points INTO buf. */
 int hjd_parse_header(const uint8_t *buf, size_t size, hjd_jpeg_data *out);
+/* The same walk with flags: HJD_PARSE_CONFORMANT admits what only the reference cannot take (DC Huffman codes of
+ * 16 bits, loadjpg.cpp:562) — used by decoders created with hjd_options.conformant. */
+#define HJD_PARSE_CONFORMANT 1
+int hjd_parse_header_ex(const uint8_t *buf, size_t size, hjd_jpeg_data *out, int flags);
 
 /* Same argument order as the reference: (jdata, height, width, hFactor, vFactor).
  * rgb_out: host buffer of 3*width*height bytes (stJpegData::m_rgb).  Returns an hjd_status
@@ -118,7 +122,12 @@ typedef struct hjd_options {
     int dirty_mode;      /* restart streams on which the reference leaves the clean-resync domain:
                           * 0 = decoded the way the reference decodes them, by a sequential emulation kernel (slow, exact);
                           * 1 = refused with HJD_ERR_DIRTY_RESTART */
-    int reserved[3];
+    int conformant;      /* SURVEY §8f N4, outside the parity contract, never the default: 1 = decode as a conforming baseline
+                          * decoder would where the reference deviates — DC predictors reset at every RSTn, restart intervals
+                          * taken by the standard's rule (no DIRTY verdicts), DC codes of 16 bits accepted, IDCT with the
+                          * true cosines and round-to-nearest, colour conversion with the JFIF constants and rounding.
+                          * Chroma stays nearest-neighbour.  0 = byte-identical to the reference. */
+    int reserved[2];
 } hjd_options;
 
 hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);

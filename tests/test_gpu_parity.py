@@ -540,3 +540,117 @@ def test_statuses(hjd, dec, golden):
     assert st[2] == hjd.HJD_ERR_CORRUPT
     assert st[3] == hjd.HJD_ERR_NOT_JPEG
     assert st[4] == 0 and outs[4] is not None
+
+
+# ---- conformant mode (opt-in, outside the parity contract) --------------------------------------
+
+UNZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _conformant_model(hjd, dec, data, ri):
+    """float64 model of what a conforming baseline decoder with nearest-neighbour chroma computes, from the
+    coefficients the (default-mode, reference-exact) entropy stage delivers: DC predictors restarted at every
+    interval, every component dequantised with its own table, exact IDCT, rounding, JFIF colour constants."""
+    st, jd = hjd.parse_header(data)
+    assert st == 0
+    w, h, hf, vf = jd.width, jd.height, jd.hfactor, jd.vfactor
+    mx, my = -(-w // (8 * hf)), -(-h // (8 * vf))
+    nby = hf * vf
+    nb = nby + 2
+    b = dec.prepare([data])
+    b.run()
+    assert b.finish() == [0]
+    co = b.download_coefs(0, mx * my * nb).astype(np.int64).reshape(mx * my, nb, 64)
+    b.close()
+    if ri:  # the reference carries the predictors across intervals; undo that per component
+        comp_last = {0: nby - 1, 1: nby, 2: nby + 1}
+        dc = co[:, :, 0].copy()
+        for m in range(mx * my):
+            s0 = m - m % ri
+            if s0:
+                for k in range(nb):
+                    c = 0 if k < nby else k - nby + 1
+                    co[m, k, 0] = ((dc[m, k] - dc[s0 - 1, comp_last[c]] + 32768) % 65536) - 32768
+    qt = [np.array(list(jd.qtable[c]), np.float64) for c in (1, 2, 3)]
+    x = np.arange(8)
+    cs = np.cos((2 * x[:, None] + 1) * x[None, :] * np.pi / 16)       # [x][u]
+    cu = np.where(x == 0, np.sqrt(0.5), 1.0)
+    planes = [np.zeros((my * 8 * vf, mx * 8 * hf)), np.zeros((my * 8, mx * 8)), np.zeros((my * 8, mx * 8))]
+    for m in range(mx * my):
+        r, c0 = divmod(m, mx)
+        for k in range(nb):
+            c = 0 if k < nby else k - nby + 1
+            F = np.zeros(64)
+            F[UNZZ] = co[m, k] * qt[c]                                   # natural order v*8+u
+            F = F.reshape(8, 8)                                          # [v][u]
+            t = 0.25 * np.einsum("yv,v,vu,u,xu->yx", cs, cu, F, cu, cs)
+            px = np.clip(np.floor(t + 128.5), 0, 255)
+            if c == 0:
+                by, bx = divmod(k, hf)
+                planes[0][r * 8 * vf + by * 8:r * 8 * vf + by * 8 + 8, c0 * 8 * hf + bx * 8:c0 * 8 * hf + bx * 8 + 8] = px
+            else:
+                planes[c][r * 8:r * 8 + 8, c0 * 8:c0 * 8 + 8] = px
+    Y = planes[0][:h, :w]
+    Cb = np.repeat(np.repeat(planes[1], vf, 0), hf, 1)[:h, :w] - 128.0
+    Cr = np.repeat(np.repeat(planes[2], vf, 0), hf, 1)[:h, :w] - 128.0
+    rgb = np.stack([Y + 1.402 * Cr, Y - 0.344136 * Cb - 0.714136 * Cr, Y + 1.772 * Cb], -1)
+    return np.clip(np.floor(rgb + 0.5), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,hf,vf,ri,three", [(250, 187, 2, 2, 0, False), (320, 240, 2, 2, 5, True), (200, 120, 1, 1, 7, True),
+                                                   (333, 100, 2, 1, 1, False)])
+def test_conformant_mode_matches_a_float64_model(hjd, dec, w, h, hf, vf, ri, three):
+    """hjd_options.conformant (outside the parity contract, never the default): DC predictors reset at
+    RSTn, each component's own quantiser, true-cosine rounding IDCT, JFIF colour with rounding.  Within +-1 of a float64
+    model (fp32 vs fp64 ties); and the DEFAULT decoder's bytes for the same input still equal the oracle's."""
+    data = T.encode_jpeg_ex(T.synth_rgb(w, h, 900 + ri, 6.0), 85, hf, vf, ri, three, T.HUFF_STD)
+    conf = hjd.Decoder(0, conformant=1)
+    st, outs = conf.decode([data])
+    conf.close()
+    assert st == [0]
+    model = _conformant_model(hjd, dec, data, ri)
+    diff = np.abs(outs[0].astype(np.int32) - model.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (int(diff.max()), float((diff > 0).mean()))
+    st, outs = dec.decode([data])
+    orc, orgb, _, _, _ = T.oracle_decode(data)
+    assert st == [0] and orc == 0 and np.array_equal(outs[0], orgb)
+
+
+def test_conformant_mode_agrees_with_libjpeg_on_444_restart_streams(hjd):
+    """The same image through Pillow (libjpeg): no chroma upsampling in 4:4:4, so only IDCT / colour rounding differ
+    (a few levels at most), while the reference-exact default mode is off by tens of levels on a DRI stream because
+    the reference never resets its DC predictors."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    data = T.synth_jpeg(320, 200, 77, 90, 1, 1, 6, 6.0)
+    lib = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(np.int32)
+    conf = hjd.Decoder(0, conformant=1)
+    st, outs = conf.decode([data])
+    conf.close()
+    assert st == [0]
+    d = np.abs(outs[0].astype(np.int32) - lib)
+    assert d.max() <= 4 and d.mean() < 0.7, (int(d.max()), float(d.mean()))
+    ref = hjd.Decoder(0)
+    st, outs = ref.decode([data])
+    ref.close()
+    assert st == [0] and np.abs(outs[0].astype(np.int32) - lib).mean() > 5.0
+
+
+def test_conformant_mode_takes_16_bit_dc_codes(hjd, dec, golden):
+    """A DC Huffman table with a 16-bit code: the reference's search stops at 15 bits (loadjpg.cpp:562), so the default
+    mode refuses the file; the conformant mode decodes it.  The fixture's DC table is edited in place: the code of its
+    last symbol (never used by this image) moves from 9 to 16 bits, which leaves every other code unchanged."""
+    d, man = golden
+    data = bytearray(open(os.path.join(d, "syn_250x187_420_q85.jpg"), "rb").read())
+    k = data.index(b"\xff\xc4")
+    assert data[k + 4] == 0x00 and data[k + 5 + 8] == 1 and data[k + 5 + 15] == 0   # DC table 0: one 9-bit code, no 16-bit code
+    data[k + 5 + 8] = 0
+    data[k + 5 + 15] = 1
+    data = bytes(data)
+    st, outs = dec.decode([data])
+    assert st == [hjd.HJD_ERR_UNSUPPORTED]
+    conf = hjd.Decoder(0, conformant=1)
+    st, outs = conf.decode([data, open(os.path.join(d, "syn_250x187_420_q85.jpg"), "rb").read()])
+    conf.close()
+    assert st == [0, 0] and np.array_equal(outs[0], outs[1])
