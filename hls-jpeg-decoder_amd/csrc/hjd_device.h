@@ -30,7 +30,9 @@
 #define HJD_LUT_SIZE (1 << HJD_LUT_BITS)
 #define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
+#ifndef HJD_SYNC_WG
 #define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
+#endif
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
@@ -67,6 +69,10 @@ struct HjdTableSet {
     uint32_t pad;
     uint16_t lut[HJD_SLOTS][HJD_LUT_SIZE];
     uint16_t sec[HJD_MAX_SEC][1 << HJD_SEC_BITS];
+    // The same tables in the form the synchronisation pass wants (it needs no values): bits 0-4 code length + value bits
+    // (0 = long code, as above), bits 5-11 zig-zag advance, bit 12 = the symbol produces an AC record.
+    uint16_t lut_s[HJD_SLOTS][HJD_LUT_SIZE];
+    uint16_t sec_s[HJD_MAX_SEC][1 << HJD_SEC_BITS];
     HjdCanon canon[HJD_SLOTS]; // per slot (component*2 + isAC)
 };
 

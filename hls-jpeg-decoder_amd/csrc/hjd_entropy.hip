@@ -50,13 +50,14 @@ __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t 
     return w + ((size_t)(i >> 6) * ((1u << lw) + 2u)) * 64u + (i & 63u);
 }
 
+template <bool SYNC_FORM>
 __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
 {
     const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * 2 / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
-    const uint4 *src = reinterpret_cast<const uint4 *>(&ts->lut[0][0]);
+    const uint4 *src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->lut_s[0][0] : &ts->lut[0][0]);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
     for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) dst[k] = src[k];
-    src = reinterpret_cast<const uint4 *>(&ts->sec[0][0]);
+    src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->sec_s[0][0] : &ts->sec[0][0]);
     dst = reinterpret_cast<uint4 *>(s_sec);
     for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) dst[k] = src[k];
 }
@@ -184,7 +185,8 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 e = 16u; // skip 16 bits: any progress will do, the result is discarded or flagged
             }
         }
-        const uint32_t len = e & 31u, s = (e >> 5) & 15u, adv = e >> 9;
+        // WRITE: e = length | value bits << 5 | advance << 9.  Synchronisation: e = (length + value bits) | advance << 5 | record << 12.
+        const uint32_t len = e & 31u, s = WRITE ? (e >> 5) & 15u : 0u, adv = WRITE ? e >> 9 : (e >> 5) & 127u;
         const bool isdc = z == 0u;
         if (WRITE) {
             // value bits + DetermineSign (loadjpg.cpp:396-409)
@@ -217,8 +219,8 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 }
                 nrec++;
             }
-        } else if (!isdc && s != 0u) {
-            nrec++;
+        } else {
+            nrec += e >> 12;
         }
         z += adv;
         tb = isdc ? pair >> 16 : tb;
@@ -347,7 +349,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
     const int ii = (int)(MODE == 0 ? P.map_syncwg[bid] : P.map_repwg[bid]);
-    static_assert(HJD_SYNC_WG == 2 * HJD_WRITE_WG, "a repair workgroup covers exactly two final-pass workgroups");
+    static_assert(HJD_SYNC_WG % HJD_WRITE_WG == 0, "a repair workgroup covers whole final-pass workgroups");
+    constexpr uint32_t R = HJD_SYNC_WG / HJD_WRITE_WG;
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
     const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
@@ -393,7 +396,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     WriteCtx W = {};
 
     if (MODE == 0) {
-        load_tables(ts, s_lut, s_sec);
+        load_tables<true>(ts, s_lut, s_sec);
         __syncthreads();
         // round 0: every subsequence from the guess (bit = its first bit, z = 0, MCU phase 0)
         uint32_t p = sp, z = 0, m = 0, nblk = 0, nrec = 0;
@@ -448,7 +451,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         }
         if (ndirty == 0) break;
         if (MODE != 0 && !tables_loaded) {
-            load_tables(ts, s_lut, s_sec);
+            load_tables<true>(ts, s_lut, s_sec);
             tables_loaded = true;
         }
         if (dirty) {
@@ -492,7 +495,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                 sb += s_lp[w0 + q];
                 sr += s_lzm[w0 + q];
             }
-            if (wg * 2u + h < im.nwritewg) P.wgsum[im.writewg0 + wg * 2u + h] = make_uint2(sb, sr);
+            if (wg * R + h < im.nwritewg) P.wgsum[im.writewg0 + wg * R + h] = make_uint2(sb, sr);
             if (wg == 0 && h == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
         }
     }
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
     if (wg * HJD_WRITE_WG >= nsub) return; // capacity-based grid: nothing in this workgroup
-    load_tables(ts, s_lut, s_sec);
+    load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
 
     const uint32_t i = wg * HJD_WRITE_WG + tid;

@@ -31,6 +31,7 @@ struct HjdParams {
     // A launch may cover only a contiguous range of images (sub-batches on separate streams): these are
     // added to blockIdx.x so that every kernel still sees batch-global workgroup / image numbers.
     uint32_t off_chunk, off_syncwg, off_repwg, off_writewg, off_img, off_dcchunk, off_group;
+    uint32_t conformant;       // hjd_options.conformant: selects the conformant instantiation of the back end
     uint32_t subseq_bits;      // power of two, 64..4096
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup

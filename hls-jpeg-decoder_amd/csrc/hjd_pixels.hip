@@ -182,6 +182,9 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
 
 // ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
 
+// CONF: conformant mode (hjd_options.conformant) — a separate instantiation, so that the default kernel carries none of
+// its branches (as run-time branches they cost 4 % of the kernel); every image of a batch has the decoder's setting.
+template <bool CONF>
 __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
 {
     __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index = slot u*8+v (u = horizontal frequency); +2 pad: bank spread
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     int dc = 0;
     if (tid <= KB) be = P.blk[gm.y + tid];
     if (tid < KB) dc = P.dca[gm.y + tid];
-    const bool conf = im.conformant != 0;
+    constexpr bool conf = CONF;
     if (tid < 64) {
         s_cos[tid] = conf ? c_cos_true[(tid & 7) * 8 + (tid >> 3)] : c_cos[(tid & 7) * 8 + (tid >> 3)];
         // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
@@ -350,11 +353,8 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __syncthreads();
 
     // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932) + output layout
-    if (conf) { // conformant mode (opt-in): rounding colour stage
-        if (im.out_format == 1) color_store<true, true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
-        else color_store<false, true>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
-    } else if (im.out_format == 1) color_store<true, false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
-    else color_store<false, false>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    if (im.out_format == 1) color_store<true, CONF>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
+    else color_store<false, CONF>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
 }
 
 // Test hook: the colour stage, alone, over every (Y, Cb, Cr) triple.  Output: 3 bytes
@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void k_color_table(uint8_t *out)
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s)
 {
     if (!ngroups) return 0;
-    hipLaunchKernelGGL(k_idct_color, dim3(ngroups), dim3(256), 0, s, P);
+    if (P.conformant) hipLaunchKernelGGL(k_idct_color<true>, dim3(ngroups), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(k_idct_color<false>, dim3(ngroups), dim3(256), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -145,6 +145,7 @@ struct hjd_batch {
 static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is_dc)
 {
     memset(ts.lut[ti], 0, sizeof(ts.lut[ti]));
+    memset(ts.lut_s[ti], 0, sizeof(ts.lut_s[ti]));
     unsigned code = 0, idx = 0;
     for (int k = 1; k <= 16; k++) {
         for (unsigned j = 0; j < h.bits[k]; j++, idx++, code++) {
@@ -160,22 +161,31 @@ static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is
                 else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
             }
             const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
+            const uint16_t es = (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 12 : 0u)); // synchronisation form
             if (k <= HJD_LUT_BITS) {
                 const unsigned lo = code << (HJD_LUT_BITS - k), cnt = 1u << (HJD_LUT_BITS - k);
-                for (unsigned q = 0; q < cnt; q++) ts.lut[ti][lo + q] = e;
+                for (unsigned q = 0; q < cnt; q++) {
+                    ts.lut[ti][lo + q] = e;
+                    ts.lut_s[ti][lo + q] = es;
+                }
             } else {
                 const unsigned prefix = code >> (k - HJD_LUT_BITS);
                 uint16_t &pe = ts.lut[ti][prefix];
                 if (pe == 0) {
                     if (ts.nsec >= HJD_MAX_SEC) return false;
                     memset(ts.sec[ts.nsec], 0, sizeof(ts.sec[0]));
+                    memset(ts.sec_s[ts.nsec], 0, sizeof(ts.sec_s[0]));
                     pe = (uint16_t)((ts.nsec + 1) << 5);
+                    ts.lut_s[ti][prefix] = pe;
                     ts.nsec++;
                 }
                 const unsigned si = (pe >> 5) - 1;
                 const unsigned rem = code & ((1u << (k - HJD_LUT_BITS)) - 1);
                 const unsigned sbits = HJD_SEC_BITS - (k - HJD_LUT_BITS);
-                for (unsigned q = 0; q < (1u << sbits); q++) ts.sec[si][(rem << sbits) + q] = e;
+                for (unsigned q = 0; q < (1u << sbits); q++) {
+                    ts.sec[si][(rem << sbits) + q] = e;
+                    ts.sec_s[si][(rem << sbits) + q] = es;
+                }
             }
         }
         code <<= 1;
@@ -513,6 +523,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->out_total = out_cur;
     b->state.assign(b->nimg, HjdImageState{});
     HjdParams &P = b->P;
+    P.conformant = d->conformant ? 1u : 0u;
     P.subseq_bits = S;
     P.log2_words = 0;
     while ((32u << P.log2_words) < S) P.log2_words++;

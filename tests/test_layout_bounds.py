@@ -80,7 +80,7 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         assert o.nrepwg * T_ >= nsub                     # k_repair
         assert o.nwritewg * WW >= nsub                   # k_write, k_scan
         assert o.nwritewg <= o.wgsum_entries
-        assert 2 * (o.nrepwg - 1) < o.nwritewg + 1       # k_repair_totals writes wgsum[2*wg + h] only below nwritewg (guarded)
+        assert (T_ // WW) * (o.nrepwg - 1) < o.nwritewg + 1   # k_repair_totals writes wgsum[R*wg + h] only below nwritewg (guarded)
         # --- LDS of the entropy kernels: tables, state arrays, then one window of phase_words + 2 words per lane
         assert o.lds_bytes_sync >= (o.lds_state_word + 5 * T_ + 16 + (T_ // 64) * (o.phase_words + 2) * 64) * 4
         assert o.lds_bytes_write >= (o.lds_state_word + 48 + (WW // 64) * (o.phase_words + 2) * 64) * 4
