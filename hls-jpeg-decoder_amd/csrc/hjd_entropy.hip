@@ -128,18 +128,19 @@ struct WriteCtx {
     uint4 *blk;
     uint32_t nblocks;
     const uint8_t *slot_of; // LDS: zig-zag index -> slot u*8+v
-    uint32_t mlo, mhi;      // slots filled by the records of the block in progress (this subsequence's part of it)
+    unsigned long long mask; // slots filled by the records of the block in progress (this subsequence's part of it)
     uint32_t bfirst;        // first record of the block in progress, or ~0 when the block began in an earlier subsequence
     uint32_t bdc;
+    uint32_t tag;           // block bits of a record: (block & 127) << 22, | HJD_REC_ORPHAN while the block began elsewhere
 };
 
 // The entry of block b once its last symbol is decoded (or, from the caller, when the subsequence ends inside
 // it): written by the lane that decoded the block's DC symbol (bfirst != ~0), one 16-byte store.
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
-    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint4(W.bfirst, W.bdc, W.mlo, W.mhi);
+    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint4(W.bfirst, W.bdc, (uint32_t)W.mask, (uint32_t)(W.mask >> 32));
     W.bfirst = 0xFFFFFFFFu;
-    W.mlo = W.mhi = 0u;
+    W.mask = 0ull;
 }
 
 // Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
@@ -189,25 +190,25 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         const uint32_t len = e & 31u, s = WRITE ? (e >> 5) & 15u : 0u, adv = WRITE ? e >> 9 : (e >> 5) & 127u;
         const bool isdc = z == 0u;
         if (WRITE) {
-            // value bits + DetermineSign (loadjpg.cpp:396-409)
-            const uint32_t vb = ((win << len) >> 1) >> (31u - s);
-            const int val = (int)vb - ((vb < ((1u << s) >> 1)) ? (int)((1u << s) - 1u) : 0);
+            // value bits + DetermineSign (loadjpg.cpp:396-409): v < 2^(s-1), i.e. leading value bit 0, means v - (2^s - 1)
+            const uint32_t t = win << len;
+            const uint32_t vb = (t >> 1) >> (31u - s);
+            const int val = (int)vb - (int)(~(uint32_t)((int)t >> 31) & ((1u << s) - 1u));
             if (isdc) {
                 W.bfirst = nrec;
                 W.bdc = (uint32_t)(int)(int16_t)val;
+                W.tag = (nblk & 127u) << 22;
                 // the reference looks for a marker again between the DC code and its extra bits
                 if (RESTART && !rc.conf && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
             } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
                 const uint32_t zw = z + adv - 1u;
                 const uint32_t slot = W.slot_of[zw & 63u];
-                uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | ((nblk & 127u) << 22) |
-                             (W.bfirst == 0xFFFFFFFFu ? HJD_REC_ORPHAN : 0u);
+                uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag;
                 if (zw > 63u) {
                     flags |= HJD_FLAG_OVERRUN;
                     w = HJD_REC_PAD;
                 } else {
-                    W.mlo |= slot < 32u ? 1u << slot : 0u;
-                    W.mhi |= slot < 32u ? 0u : 1u << (slot - 32u);
+                    W.mask |= 1ull << slot;
                 }
                 W.r0 = W.r1;
                 W.r1 = W.r2;
@@ -620,7 +621,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 
     uint32_t z = zm & 0xFFu, m = zm >> 8;
     WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks,
-                  s_slot, 0u, 0u, 0xFFFFFFFFu, 0u};
+                  s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
+    W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun elsewhere
     const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
     decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0);
     if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the subsequence ends inside a block
