@@ -290,14 +290,18 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
             uint32_t blk;
             if (s < nluma) blk = (s >> lnby) * nb + (s & (nby - 1u));
             else blk = ((s - nluma) >> 1) * nb + nby + ((s - nluma) & 1u);
-            float acc0[8], acc1[8];
-#pragma unroll
-            for (int y = 0; y < 8; y++) acc0[y] = acc1[y] = 0.0f;
             const uint2 mk = *reinterpret_cast<const uint2 *>(&s_mask[blk][0]);
             const int16_t *cf = &s_coef[blk][0];
+            // The first term of the sum is the DC term whenever slot 0 is filled: COS[x][0] = COS[y][0] = 1.0f, both
+            // multiplications are exact and 0.0f + t = t, so the accumulators simply START at C(0)C(0)*DC — one
+            // whole pass of the term loop less for every block (all 16 teams of a wave have it).
+            const float tdc = (mk.x & 1u) ? s_kk[0] * (float)cf[0] : 0.0f;
+            float acc0[8], acc1[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) acc0[y] = acc1[y] = tdc;
 #pragma unroll
             for (int half = 0; half < 2; half++) { // u = 0..3, then u = 4..7: ascending set bits = the term order
-                uint32_t m32 = half ? mk.y : mk.x;
+                uint32_t m32 = half ? mk.y : (mk.x & ~1u);
                 while (m32) {
                     const uint32_t j = half * 32u + (uint32_t)__ffs((int)m32) - 1u;
                     m32 &= m32 - 1u;
