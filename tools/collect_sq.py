@@ -18,6 +18,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair_first", "k_repair_totals": "huff_repair", "k_write": "huff_write",
@@ -37,7 +38,7 @@ def main():
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             seen = set()
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0]
+                k = re.sub(r"<.*", "", r["Kernel_Name"].split("(")[0].replace("void ", "")).strip()
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[k][r["Counter_Name"]] += 1
                 key = (f, r["Dispatch_Id"])

@@ -13,6 +13,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair", "k_write": "huff_write",
@@ -26,7 +27,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = re.sub(r"<.*", "", r["Kernel_Name"].split("(")[0].replace("void ", "")).strip()
             tot[k] += float(r["Counter_Value"])
             n[k] += 1
     return {k: tot[k] / n[k] for k in tot}, n
