@@ -97,9 +97,22 @@ __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const 
     const float f1 = bgr ? b1 : r1, l1 = bgr ? r1 : b1;
     const float f2 = bgr ? b2 : r2, l2 = bgr ? r2 : b2;
     const float f3 = bgr ? b3 : r3, l3 = bgr ? r3 : b3;
-    d0 = put_u8<CONF>(f1, 3, put_u8<CONF>(l0, 2, put_u8<CONF>(g0, 1, put_u8<CONF>(f0, 0, 0u))));
-    d1 = put_u8<CONF>(g2, 3, put_u8<CONF>(f2, 2, put_u8<CONF>(l1, 1, put_u8<CONF>(g1, 0, 0u))));
-    d2 = put_u8<CONF>(l3, 3, put_u8<CONF>(g3, 2, put_u8<CONF>(f3, 1, put_u8<CONF>(l2, 0, 0u))));
+    if (CONF) {
+        d0 = put_u8<CONF>(f1, 3, put_u8<CONF>(l0, 2, put_u8<CONF>(g0, 1, put_u8<CONF>(f0, 0, 0u))));
+        d1 = put_u8<CONF>(g2, 3, put_u8<CONF>(f2, 2, put_u8<CONF>(l1, 1, put_u8<CONF>(g1, 0, 0u))));
+        d2 = put_u8<CONF>(l3, 3, put_u8<CONF>(g3, 2, put_u8<CONF>(f3, 1, put_u8<CONF>(l2, 0, 0u))));
+    } else {
+        // (int) truncates, v_cvt_pk_u8_f32 converts in the wave's fp32 rounding mode: switch that to round-toward-zero for
+        // the twelve conversions (one statement, so that no other arithmetic can be scheduled inside) instead of a
+        // v_trunc_f32 in front of each.  Negative values still saturate to 0, like Clamp((int)x).
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+                     "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\tv_cvt_pk_u8_f32 %0, %4, 1, %0\n\tv_cvt_pk_u8_f32 %0, %5, 2, %0\n\tv_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+                     "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\tv_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+                     "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\tv_cvt_pk_u8_f32 %2, %12, 1, %2\n\tv_cvt_pk_u8_f32 %2, %13, 2, %2\n\tv_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+                     : "v"(f0), "v"(g0), "v"(l0), "v"(f1), "v"(g1), "v"(l1), "v"(f2), "v"(g2), "v"(l2), "v"(f3), "v"(g3), "v"(l3));
+    }
 }
 
 // Phase 3 of k_idct_color: nearest-neighbour chroma (loadjpg.cpp:911-912), colour, clip at the image edge
