@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhjd.so")
+LIB_PATH = os.environ.get("HJD_LIB") or os.path.join(_HERE, "lib", "libhjd.so")  # HJD_LIB: an experiment build of the same library
 
 HJD_OK, HJD_ERR_NOT_JPEG, HJD_ERR_UNSUPPORTED, HJD_ERR_CORRUPT, HJD_ERR_DIRTY_RESTART, HJD_ERR_NO_DEVICE, \
     HJD_ERR_ARG, HJD_ERR_IO, HJD_ERR_INTERNAL = range(9)

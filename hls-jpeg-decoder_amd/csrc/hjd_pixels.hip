@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     __shared__ float s_kk[64];            // C(u)*C(v) by slot
     __shared__ __attribute__((aligned(4))) uint8_t s_qt[3][64]; // by slot
     __shared__ uint32_t s_range[2];       // records of the group: [first, end)
+    __shared__ uint32_t s_hist[64];       // counting sort of the blocks by number of terms: bin fill, then bin start
+    __shared__ uint8_t s_order[MAXGB];    // blocks in descending order of their term count
 
     const uint32_t tid = threadIdx.x;
     const uint32_t bid = blockIdx.x + P.off_group;
@@ -220,8 +222,6 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     const uint32_t K = min((uint32_t)HJD_GROUP_MCUS, im.mcux - mcu_first);
     const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t KB = K * nb;
-    const uint32_t lnby = nby >> 1; // log2 for 1, 2, 4
-    const uint32_t nluma = K << lnby;
 
     // block entries (first record, DC difference, slot mask) and predicted DC — independent of the image fields
     uint4 be = make_uint4(0u, 0u, 0u, 0u);
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         s_kk[tid] = (u == 0) ? (v == 0 ? (conf ? 0.5f : 0x1.fffffep-2f) : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
     }
     if (tid < 48) reinterpret_cast<uint32_t *>(&s_qt[0][0])[tid] = reinterpret_cast<const uint32_t *>(&im.qt[0][0])[tid];
+    if (tid >= 64 && tid < 128) s_hist[tid - 64] = 0u;
     if (tid <= KB) {
         const uint32_t first = min(be.x, im.rec_cap);
         if (tid == 0) s_range[0] = first;
@@ -291,18 +292,48 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         }
     }
     __syncthreads();
+#if defined(HJD_IDCT_CUT) && HJD_IDCT_CUT == 1 // instruction accounting only (tools/idct_phase_counts.sh): stop after phase 1
+    P.out[im.out_off + (size_t)lg * 256u + tid] = (uint8_t)s_coef[tid % MAXGB][tid & 63];
+    return;
+#endif
+
+    // The 16 teams of a wave walk their blocks' terms in lock step, so a wave pays for its LONGEST block: blocks are
+    // dealt to the teams in descending order of their term count (counting sort over the group: bin = 63 - key,
+    // key = max(terms in slots 1-31, 4 x terms in slots 32-63), the two loops below).  On the 4K synthetic set this
+    // takes the term loop from 13.1 to 11.0 iterations per wave pass (tools/idct_model.py).
+    uint32_t bin = 0, rank = 0;
+    if (tid < KB) {
+        const uint2 mk = *reinterpret_cast<const uint2 *>(&s_mask[tid][0]);
+        bin = 63u - min(63u, max((uint32_t)__popc(mk.x & ~1u), 4u * (uint32_t)__popc(mk.y)));
+        rank = atomicAdd(&s_hist[bin], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive prefix over the 64 bins, one wave
+        const uint32_t c = s_hist[tid];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if ((int)tid >= d) incl += o;
+        }
+        s_hist[tid] = incl - c;
+    }
+    __syncthreads();
+    if (tid < KB) s_order[s_hist[bin] + rank] = (uint8_t)tid;
+    __syncthreads();
 
     // phase 2: IDCT_calc / PerformIDCT (loadjpg.cpp:105-140).  Team of 4 lanes = one block; lane = two output
     // columns x0, x0+1 with 2 x 8 row accumulators.  Terms are added in the reference's order (u outer, v
     // inner = ascending slot); empty slots would add +-0 and are skipped.
-    // term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].  Blocks are dealt component-major: team s < nluma
-    // takes a luma block, the rest the chroma blocks.
+    // term = (((C(u)C(v)) * b) * COS[x][u]) * COS[y][v].
     {
         const uint32_t x0 = (tid & 3) * 2;
-        for (uint32_t s = tid >> 2; s < KB; s += 64) {
-            uint32_t blk;
-            if (s < nluma) blk = (s >> lnby) * nb + (s & (nby - 1u));
-            else blk = ((s - nluma) >> 1) * nb + nby + ((s - nluma) & 1u);
+        // sorted positions 0..63 go to the four waves in order; positions 64.. (the shortest blocks) to waves 3, 2 — the
+        // waves whose first blocks were the shortest
+        for (uint32_t pass = 0; pass < 2; pass++) {
+            const uint32_t s = pass == 0 ? (tid >> 2) : 64u + (3u - (tid >> 6)) * 16u + ((tid >> 2) & 15u);
+            if (s >= KB) continue;
+            const uint32_t blk = s_order[s];
             const uint2 mk = *reinterpret_cast<const uint2 *>(&s_mask[blk][0]);
             const int16_t *cf = &s_coef[blk][0];
             // The first term of the sum is the DC term whenever slot 0 is filled: COS[x][0] = COS[y][0] = 1.0f, both
@@ -368,6 +399,10 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
         }
     }
     __syncthreads();
+#if defined(HJD_IDCT_CUT) && HJD_IDCT_CUT == 2 // stop after phase 2
+    P.out[im.out_off + (size_t)lg * 256u + tid] = s_pix[tid % MAXGB][tid & 63];
+    return;
+#endif
 
     // phase 3: YCrCB_to_RGB24_Block8x8 (loadjpg.cpp:884-932) + output layout
     if (im.out_format == 1) color_store<true, CONF>(im, P.out + im.out_off, s_pix, tid, mrow, mcu_first, K, lg);
