@@ -31,11 +31,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# fp32 VALU issue, G wave-instructions/s: nominal = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide's
-# figure); measured = v_mul_f32 at 8 waves per SIMD, independent accumulators, on this chip (tools/pk_rate.hip,
-# profiles/r02_pk_rate.txt: 4.44 cycles per wave-instruction per SIMD; v_pk_mul_f32 / v_pk_add_f32 4.8-5.0)
+# VALU issue, G wave-instructions/s: nominal = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (the guide's
+# figure); measured = the issue cost of the instruction kinds these kernels are made of, on this chip, 8 waves per SIMD,
+# independent chains (tools/valu_rate.hip, profiles/r02_valu_rate.txt), in cycles per wave-instruction per SIMD at 2.4 GHz:
+# v_mov 2.4; v_and / v_add_u32 / v_add_f32 / v_mul_f32 2.8-3.1; shifts, v_lshl_add, v_bfe, v_ffbl, conversions, v_trunc, v_fma,
+# v_max3, compares, integer multiplies 4.2-4.7; v_pk_mul_f32 / v_pk_add_f32 5.0.  The kernels' mix (a third packed, half of
+# the 4.2+ class, a sixth cheap) averages about 4.3.
 VALU_PEAK_NOMINAL_GINST = 1024 * 2.4 / 2
-VALU_PEAK_MEASURED_GINST = 1024 * 2.4 / 4.44
+VALU_CYCLES_MIX = 4.3
+VALU_PEAK_MEASURED_GINST = 1024 * 2.4 / VALU_CYCLES_MIX
 
 
 def host_cores():
@@ -338,7 +342,9 @@ def main():
             roof["valu"] = {"bound": "valu", "achieved": round(g, 1), "peak": round(VALU_PEAK_MEASURED_GINST, 1),
                             "peak_nominal": VALU_PEAK_NOMINAL_GINST, "unit": "G wave-instr/s",
                             "frac": round(g / VALU_PEAK_MEASURED_GINST, 4), "frac_of_nominal": round(g / VALU_PEAK_NOMINAL_GINST, 4),
-                            "wave_insts_per_step": valu_step, "scope": "whole step, all kernels, overlapped streams"}
+                            "wave_insts_per_step": valu_step, "cycles_per_inst_per_simd": round(1024 * 2.4 / g, 2),
+                            "cycles_per_inst_of_the_mix": VALU_CYCLES_MIX, "cost_table": "profiles/r02_valu_rate.txt",
+                            "scope": "whole step, all kernels, overlapped streams"}
         out = {
             "metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)",
             "value": round(value, 1),
