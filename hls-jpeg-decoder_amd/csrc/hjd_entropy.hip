@@ -53,8 +53,8 @@ __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t 
 template <bool SYNC_FORM>
 __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
 {
-    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * 2 / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
-    const uint4 *src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->lut_s[0][0] : &ts->lut[0][0]);
+    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * (SYNC_FORM ? 4 : 2) / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->lut_s[0][0][0] : &ts->lut[0][0]);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
     for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) dst[k] = src[k];
     src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->sec_s[0][0] : &ts->sec[0][0]);
@@ -62,11 +62,12 @@ __device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_l
     for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) dst[k] = src[k];
 }
 
-// (DC | AC << 16) byte offsets of a component's primary tables, from the packed slot map
-__device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp)
+// (DC | AC << 16) byte offsets of a component's primary tables, from the packed slot map; entry_bytes = 2, or 4 for
+// the synchronisation form with its two entries per index
+__device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp, uint32_t entry_bytes)
 {
-    const uint32_t dc = ((slot_pack >> (comp * 8u)) & 7u) * (HJD_LUT_SIZE * 2u);
-    const uint32_t ac = ((slot_pack >> (comp * 8u + 4u)) & 7u) * (HJD_LUT_SIZE * 2u);
+    const uint32_t dc = ((slot_pack >> (comp * 8u)) & 7u) * (HJD_LUT_SIZE * entry_bytes);
+    const uint32_t ac = ((slot_pack >> (comp * 8u + 4u)) & 7u) * (HJD_LUT_SIZE * entry_bytes);
     return dc | (ac << 16);
 }
 
@@ -158,7 +159,7 @@ __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 template <bool WRITE, bool RESTART>
 __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
                                             uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
-                                            uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t &nblk,
+                                            uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t pair_lim, uint32_t &nblk,
                                             uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
     ReaderLds rd;
@@ -175,7 +176,23 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
     while (p < end && (!WRITE || nblk < W.nblocks)) {
         rd.prefetch();
         const uint32_t win = rd.window();
-        uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
+        uint32_t e;
+        if (WRITE) {
+            e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
+        } else {
+            // synchronisation form: [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The
+            // pair is taken while the first symbol cannot end the block (an AC advance is at most 16) and the second
+            // still starts inside the subsequence (a step is at most 31 bits): the states passed on are then exactly
+            // those of the symbol-by-symbol walk of the final pass.  Restart streams keep to single steps (the marker
+            // rules look at every symbol boundary).
+            const uint16_t *ep = reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
+            const uint32_t e1 = ep[0];
+            e = e1;
+            if (!RESTART) {
+                const uint32_t e2 = ep[1];
+                e = (z < 48u && p < pair_lim) ? e2 : e1;
+            }
+        }
         if ((e & 31u) == 0u) {
             // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
             // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
@@ -221,7 +238,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 nrec++;
             }
         } else {
-            nrec += e >> 12;
+            nrec += e >> 14;
         }
         z += adv;
         tb = isdc ? pair >> 16 : tb;
@@ -306,6 +323,7 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
     const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, E.total_bits);
+    const uint32_t pair_lim = end > 32u ? end - 32u : 0u; // two-symbol steps of the synchronisation pass stop short of the row's end
     RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
     if (im.restart && active) {
         rc.nmark = E.nmark;
@@ -326,8 +344,8 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
         if (go) {
             const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
             for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-            if (im.restart) decode_span<WRITE, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
-            else decode_span<WRITE, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
+            if (im.restart) decode_span<WRITE, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+            else decode_span<WRITE, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
         }
     }
 }
@@ -368,8 +386,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 
     // LDS: tables | per-slot state (end state, counts, work list) | staging windows
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
-    uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
-    uint32_t *s_ep = s_dyn + P.lds_state_word;
+    uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word_s);
+    uint32_t *s_ep = s_dyn + P.lds_state_word_s;
     uint32_t *s_ezm = s_ep + T;
     uint32_t *s_cnt = s_ezm + T;
     uint32_t *s_lp = s_cnt + T;   // work list: start bit position ...
@@ -382,9 +400,9 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     E.P = &P;
     E.im = &im;
     E.L = {s_lut, s_sec};
-    E.tabY = table_pair(ts->slot_pack, 0);
-    E.tabCb = table_pair(ts->slot_pack, 1);
-    E.tabCr = table_pair(ts->slot_pack, 2);
+    E.tabY = table_pair(ts->slot_pack, 0, 4u);
+    E.tabCb = table_pair(ts->slot_pack, 1, 4u);
+    E.tabCr = table_pair(ts->slot_pack, 2, 4u);
     E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
     E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
     E.total_bits = total_bits;
@@ -594,9 +612,9 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     E.P = &P;
     E.im = &im;
     E.L = {s_lut, s_sec};
-    E.tabY = table_pair(ts->slot_pack, 0);
-    E.tabCb = table_pair(ts->slot_pack, 1);
-    E.tabCr = table_pair(ts->slot_pack, 2);
+    E.tabY = table_pair(ts->slot_pack, 0, 2u);
+    E.tabCb = table_pair(ts->slot_pack, 1, 2u);
+    E.tabCr = table_pair(ts->slot_pack, 2, 2u);
     E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
     E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
     E.total_bits = total_bits;

@@ -38,6 +38,8 @@ struct HjdParams {
     uint32_t phase_words;      // words of a subsequence staged in LDS at a time (power of two, <= subseq_bits / 32)
     uint32_t lds_sec_word;     // entropy kernels' dynamic LDS: word offset of the secondary tables
     uint32_t lds_state_word;   //                               word offset of the per-workgroup state arrays
+    uint32_t lds_sec_word_s;   // the same two offsets for the synchronisation kernels (their primary tables are twice as large)
+    uint32_t lds_state_word_s;
     uint32_t lds_bytes_sync;   //                               total bytes, k_sync / k_repair
     uint32_t lds_bytes_write;  //                               total bytes, k_write
 };

@@ -161,12 +161,12 @@ static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is
                 else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
             }
             const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
-            const uint16_t es = (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 12 : 0u)); // synchronisation form
+            const uint16_t es = (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 14 : 0u)); // synchronisation form
             if (k <= HJD_LUT_BITS) {
                 const unsigned lo = code << (HJD_LUT_BITS - k), cnt = 1u << (HJD_LUT_BITS - k);
                 for (unsigned q = 0; q < cnt; q++) {
                     ts.lut[ti][lo + q] = e;
-                    ts.lut_s[ti][lo + q] = es;
+                    ts.lut_s[ti][lo + q][0] = ts.lut_s[ti][lo + q][1] = es;
                 }
             } else {
                 const unsigned prefix = code >> (k - HJD_LUT_BITS);
@@ -176,7 +176,7 @@ static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is
                     memset(ts.sec[ts.nsec], 0, sizeof(ts.sec[0]));
                     memset(ts.sec_s[ts.nsec], 0, sizeof(ts.sec_s[0]));
                     pe = (uint16_t)((ts.nsec + 1) << 5);
-                    ts.lut_s[ti][prefix] = pe;
+                    ts.lut_s[ti][prefix][0] = ts.lut_s[ti][prefix][1] = pe;
                     ts.nsec++;
                 }
                 const unsigned si = (pe >> 5) - 1;
@@ -189,6 +189,24 @@ static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is
             }
         }
         code <<= 1;
+    }
+    if (!is_dc) {
+        // two AC symbols in one step of the synchronisation pass (HjdTableSet::lut_s): the bits after the first symbol
+        // (code + value bits) that the window still holds are looked up again, left-aligned and zero-padded; the pair
+        // exists if that finds a code no longer than the bits that are really there
+        for (unsigned i = 0; i < HJD_LUT_SIZE; i++) {
+            const unsigned e1 = ts.lut_s[ti][i][0];
+            const unsigned tot1 = e1 & 31u, adv1 = (e1 >> 5) & 127u;
+            if (tot1 == 0 || tot1 >= HJD_LUT_BITS || adv1 == 0 || adv1 > 16) continue; // long code, no room, invalid symbol, EOB
+            const unsigned rem = HJD_LUT_BITS - tot1;
+            const unsigned i2 = (i << tot1) & (HJD_LUT_SIZE - 1u);
+            const unsigned w2 = ts.lut[ti][i2];
+            const unsigned l2 = w2 & 31u, s2 = (w2 >> 5) & 15u, adv2 = w2 >> 9;
+            if (l2 == 0 || l2 > rem || adv2 == 0) continue;
+            const unsigned tot = tot1 + l2 + s2, rec = (e1 >> 14) + (s2 ? 1u : 0u);
+            if (tot > 31u) continue;
+            ts.lut_s[ti][i][1] = (uint16_t)(tot | ((adv1 + adv2) << 5) | (rec << 14));
+        }
     }
     return true;
 }
@@ -535,7 +553,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.phase_words = wpp;
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes_sync = (P.lds_state_word + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
+        P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
+        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
         P.lds_bytes_write = (P.lds_state_word + 48 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
@@ -787,6 +807,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->lds_bytes_sync = b.P.lds_bytes_sync;
     o->lds_bytes_write = b.P.lds_bytes_write;
     o->lds_state_word = b.P.lds_state_word;
+    o->lds_state_word_sync = b.P.lds_state_word_s;
     b.dec = nullptr;
     return HJD_OK;
 }

@@ -219,7 +219,7 @@ int hjd_test_color_table(hjd_decoder *d, uint8_t *dst, size_t dst_cap);
 typedef struct hjd_layout_info {
     uint32_t subseq_bits, sync_overlap, phase_words, sync_wg, write_wg, group_mcus, unstuff_chunk, dc_chunk, rec_run;
     uint32_t nblocks, mcux, mcuy, nb, nchunks, nsub_cap, nsyncwg, nrepwg, nwritewg, ndcchunk, ngroups, groups_per_row;
-    uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word;
+    uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word, lds_state_word_sync;
     uint64_t raw_bytes, ustream_bytes, blk_entries, dca_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
         dcsum_entries;
 } hjd_layout_info;
