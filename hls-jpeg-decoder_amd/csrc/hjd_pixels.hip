@@ -118,61 +118,70 @@ __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const 
 // Phase 3 of k_idct_color: nearest-neighbour chroma (loadjpg.cpp:911-912), colour, clip at the image edge
 // (:906-909), then either the m_rgb layout or the WriteBMP24 layout (openjpg.cpp:555-568).  A thread owns one
 // 4-pixel column of the group for good and walks chroma rows; everything that depends on the column only is
-// computed once, and the chroma products once per chroma sample row (they serve vf luma rows).
-template <bool BMP, bool CONF>
-__device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
-                                            uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
+// computed once, and the chroma products once per chroma sample row (they serve vf luma rows).  HF (1, 2 or 4,
+// hjd_parse_header) is a template parameter: the unit grid, the chroma fetch and the term sharing are then fixed
+// code; the output pointer is stepped by the row stride instead of being rebuilt, and the 12-byte store's
+// alignment is decided once per thread whenever the stride is a multiple of 4.
+template <bool BMP, bool CONF, uint32_t HF>
+__device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
+                                               uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
 {
-    const uint32_t W = im.width, H = im.height, hf = im.hf, vf = im.vf, nb = im.nb, nby = im.nby;
+    const uint32_t W = im.width, H = im.height, vf = im.vf, nb = im.nb, nby = im.nby;
     const uint32_t stride = im.out_stride;
-    const uint32_t mw = 8 * hf, mh = 8 * vf;
-    // hf, vf are 1, 2 or 4 (hjd_parse_header): index arithmetic is shifts and masks.  The unit grid is padded to
-    // HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields of the thread index.
-    const uint32_t lhf = hf >> 1, lvf = vf >> 1; // log2 for 1, 2, 4
-    const uint32_t lupr = 5 + lhf;               // log2(4-pixel units per padded row) = log2(HJD_GROUP_MCUS * 2 * hf)
-    const uint32_t ux = tid & ((1u << lupr) - 1u);
-    const uint32_t px = ux * 4;
-    const uint32_t k = px >> (3 + lhf), xin = px & (mw - 1u);
-    const uint32_t gxp = (mcu_first + k) * mw + xin;
-    if (ux < K * 2 * hf && gxp < W) { // loadjpg.cpp:907
+    constexpr uint32_t LHF = HF >> 1;      // log2 for 1, 2, 4
+    constexpr uint32_t LUPR = 5u + LHF;    // log2(4-pixel units per padded row) = log2(HJD_GROUP_MCUS * 2 * HF)
+    constexpr uint32_t MW = 8u * HF;
+    const uint32_t mh = 8u * vf, lvf = vf >> 1;
+    // The unit grid is padded to HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields of the thread index.
+    const uint32_t ux = tid & ((1u << LUPR) - 1u);
+    const uint32_t px = ux * 4u;
+    const uint32_t k = px >> (3u + LHF), xin = px & (MW - 1u);
+    const uint32_t gxp = (mcu_first + k) * MW + xin;
+    if (ux < K * 2u * HF && gxp < W) { // loadjpg.cpp:907
         const uint32_t nvalid = min(4u, W - gxp);
-        const uint32_t ycol = k * nb + (xin >> 3), ybyte = xin & 7u;
-        const uint8_t *pcb0 = &s_pix[k * nb + nby][0], *pcr0 = &s_pix[k * nb + nby + 1][0];
-        for (uint32_t cy = tid >> lupr; cy < 8u; cy += 256u >> lupr) {
+        const uint8_t *ytile = &s_pix[k * nb + (xin >> 3)][xin & 7u]; // luma tile of this column in the MCU's first tile row
+        const uint8_t *pcb0 = &s_pix[k * nb + nby][0] + (HF == 2 ? xin >> 1 : (HF == 4 ? xin >> 2 : xin));
+        const uint8_t *pcr0 = pcb0 + sizeof(s_pix[0]);
+        const uint32_t gy0 = mrow * mh;
+        // output address of (gxp, gy0) and the step to the next image row (BMP: bottom-up, openjpg.cpp:555-568)
+        uint8_t *const dst0 = BMP ? out + 54 + (size_t)(H - 1u - gy0) * stride + (size_t)gxp * 3u : out + (size_t)gy0 * stride + (size_t)gxp * 3u;
+        const ptrdiff_t rstep = BMP ? -(ptrdiff_t)stride : (ptrdiff_t)stride;
+        const bool wide = nvalid == 4u && (stride & 3u) == 0u && (reinterpret_cast<uintptr_t>(dst0) & 3u) == 0u; // every row's 12 bytes are aligned
+        for (uint32_t cy = tid >> LUPR; cy < 8u; cy += 256u >> LUPR) {
             ChromaTerms t0, t1, t2, t3;
-            if (hf == 2) { // pixels 0,1 and 2,3 share a chroma sample (cx = x/2)
-                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb0[cy * 8 + (xin >> 1)]);
-                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr0[cy * 8 + (xin >> 1)]);
-                t0 = t1 = chroma_terms<CONF>(cb2 & 0xFF, cr2 & 0xFF);
+            if (HF == 2) { // pixels 0,1 and 2,3 share a chroma sample (cx = x/2)
+                const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(&pcb0[cy * 8u]);
+                const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(&pcr0[cy * 8u]);
+                t0 = t1 = chroma_terms<CONF>(cb2 & 0xFFu, cr2 & 0xFFu);
                 t2 = t3 = chroma_terms<CONF>(cb2 >> 8, cr2 >> 8);
-            } else if (hf == 4) {
-                t0 = t1 = t2 = t3 = chroma_terms<CONF>(pcb0[cy * 8 + (xin >> 2)], pcr0[cy * 8 + (xin >> 2)]);
+            } else if (HF == 4) {
+                t0 = t1 = t2 = t3 = chroma_terms<CONF>(pcb0[cy * 8u], pcr0[cy * 8u]);
             } else {
-                const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb0[cy * 8 + xin]);
-                const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr0[cy * 8 + xin]);
-                t0 = chroma_terms<CONF>(cb4 & 0xFF, cr4 & 0xFF);
-                t1 = chroma_terms<CONF>((cb4 >> 8) & 0xFF, (cr4 >> 8) & 0xFF);
-                t2 = chroma_terms<CONF>((cb4 >> 16) & 0xFF, (cr4 >> 16) & 0xFF);
+                const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(&pcb0[cy * 8u]);
+                const uint32_t cr4 = *reinterpret_cast<const uint32_t *>(&pcr0[cy * 8u]);
+                t0 = chroma_terms<CONF>(cb4 & 0xFFu, cr4 & 0xFFu);
+                t1 = chroma_terms<CONF>((cb4 >> 8) & 0xFFu, (cr4 >> 8) & 0xFFu);
+                t2 = chroma_terms<CONF>((cb4 >> 16) & 0xFFu, (cr4 >> 16) & 0xFFu);
                 t3 = chroma_terms<CONF>(cb4 >> 24, cr4 >> 24);
             }
-            for (uint32_t dy = 0; dy < vf; dy++) {
-                const uint32_t row = (cy << lvf) + dy;
-                const uint32_t gy = mrow * mh + row;
-                if (gy >= H) break; // loadjpg.cpp:908
-                const uint32_t ypix = *reinterpret_cast<const uint32_t *>(&s_pix[ycol + ((row >> 3) << lhf)][(row & 7) * 8 + ybyte]);
+            const uint32_t row0 = cy << lvf;
+            uint8_t *dst = dst0 + (ptrdiff_t)row0 * rstep;
+            for (uint32_t dy = 0; dy < vf; dy++, dst += rstep) {
+                const uint32_t row = row0 + dy;
+                if (gy0 + row >= H) break; // loadjpg.cpp:908
+                const uint32_t ypix = *reinterpret_cast<const uint32_t *>(ytile + (row >> 3) * (HF * (uint32_t)sizeof(s_pix[0])) + (row & 7u) * 8u);
                 uint32_t d0, d1, d2;
                 rgb12<BMP, CONF>(ypix, t0, t1, t2, t3, d0, d1, d2);
-                uint8_t *dst = BMP ? out + 54 + (size_t)(H - 1 - gy) * stride + (size_t)gxp * 3 : out + (size_t)gy * stride + (size_t)gxp * 3;
-                if (nvalid == 4 && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0)) {
+                if (wide || (nvalid == 4u && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0u)) {
                     struct __attribute__((packed, aligned(4))) Px12 { uint32_t a, b, c; };
                     Px12 v12 = {d0, d1, d2};
                     *reinterpret_cast<Px12 *>(dst) = v12; // one 12-byte store: a wave writes 768 contiguous bytes
                 } else {
                     const uint32_t dd[3] = {d0, d1, d2};
-                    for (uint32_t j = 0; j < nvalid * 3; j++) dst[j] = (uint8_t)(dd[j >> 2] >> ((j & 3) * 8));
+                    for (uint32_t j = 0; j < nvalid * 3u; j++) dst[j] = (uint8_t)(dd[j >> 2] >> ((j & 3u) * 8u));
                 }
                 if (BMP && gxp + nvalid == W) // row padding (openjpg.cpp:563-567), written as zeros
-                    for (uint32_t q = 3 * W; q < stride; q++) out[54 + (size_t)(H - 1 - gy) * stride + q] = 0;
+                    for (uint32_t q = 3u * W; q < stride; q++) dst[(ptrdiff_t)q - (ptrdiff_t)(gxp * 3u)] = 0;
             }
         }
     }
@@ -191,6 +200,15 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
         else if (tid == 28) v = 24;
         out[tid] = (uint8_t)v;
     }
+}
+
+template <bool BMP, bool CONF>
+__device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
+                                            uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
+{
+    if (im.hf == 2) color_store_hf<BMP, CONF, 2u>(im, out, s_pix, tid, mrow, mcu_first, K, lg);
+    else if (im.hf == 1) color_store_hf<BMP, CONF, 1u>(im, out, s_pix, tid, mrow, mcu_first, K, lg);
+    else color_store_hf<BMP, CONF, 4u>(im, out, s_pix, tid, mrow, mcu_first, K, lg);
 }
 
 // ---- stage 4: dequantise + IDCT + upsample + colour + store -----------------------------------
