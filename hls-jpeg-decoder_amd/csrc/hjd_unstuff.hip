@@ -16,28 +16,30 @@
 // With DRI the reference resynchronises on any FF xx it finds at a block start (loadjpg.cpp:535-550):
 // such pairs are taken OUT of the stream and their positions recorded (mark mask, bit j = the pair's
 // second byte), so that the entropy kernels can treat the intervals between them separately.
+//
+// Only a lane that holds a 0xFF byte, follows one, or holds the end of the scan can drop anything (about one
+// lane in sixteen on entropy-coded data).  Those lanes are put on a list and worked off densely by the first
+// lanes of the workgroup with the byte-by-byte rule below; all others keep their 16 bytes and move them with
+// four funnel shifts.  (Every wave holds some such lane, so leaving the rule inside the per-lane code made
+// every wave pay for it: 199 + 508 instructions per lane in round 2's first version, now about 70 + 200.)
 
-__device__ __forceinline__ uint32_t unstuff_keepmask(const HjdImage &im, const uint8_t *raw, uint32_t lc,
-                                                      uint4 *vout, uint8_t *s_edge, uint32_t *markmask)
+#define UNSTUFF_T 256
+
+struct UnstuffLds {
+    uint4 raw[UNSTUFF_T];      // the chunk as loaded
+    uint32_t res[UNSTUFF_T];   // listed lanes: keep mask | mark mask << 16
+    uint16_t list[UNSTUFF_T];  // lanes that may drop bytes
+    uint32_t pn[2];            // byte before the chunk, byte after it
+    uint32_t n;                // entries of the list
+    uint32_t w[17];            // block scan scratch
+};
+
+// The rule itself, for the 16 bytes of one lane: returns the keep mask, *markmask = bytes that are the second byte of a
+// marker pair (restart mode).  prev = the byte before the lane's first, next = the byte after its last.
+__device__ __forceinline__ uint32_t keepmask_rule(bool rst, const uint4 v, uint32_t prev, uint32_t next, int nvalid, uint32_t *markmask)
 {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t off = lc * HJD_UNSTUFF_CHUNK + tid * 16;
-    const uint8_t *base = raw + im.raw_off + off;
-    uint4 v = *reinterpret_cast<const uint4 *>(base);
-    *vout = v;
-    s_edge[tid] = (uint8_t)(v.w >> 24);        // last byte, for the next lane
-    s_edge[256 + tid] = (uint8_t)(v.x & 0xFF); // first byte, for the previous lane
-    __syncthreads();
-    uint32_t prev, next;
-    if (tid == 0) prev = (lc == 0) ? 0u : base[-1];
-    else prev = s_edge[tid - 1];
-    if (tid == 255) next = base[16];
-    else next = s_edge[256 + tid + 1];
-    int nvalid = (int)im.scan_len - (int)off;
-    nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
     if (nvalid < 16) next = 0; // the scan ends inside this lane
-    const bool rst = im.restart != 0;
-    uint32_t words[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
     uint32_t mask = 0, marks = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -62,22 +64,68 @@ __device__ __forceinline__ uint32_t unstuff_keepmask(const HjdImage &im, const u
     return mask;
 }
 
-__global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
+__device__ __forceinline__ int lane_nvalid(const HjdImage &im, uint32_t lc, uint32_t lane)
 {
-    __shared__ uint8_t s_edge[512];
-    __shared__ uint32_t s_w[17];
+    const int nv = (int)im.scan_len - (int)(lc * HJD_UNSTUFF_CHUNK + lane * 16u);
+    return nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+}
+
+// Front end of both kernels: loads the chunk, decides which lanes need the rule, applies it to those.  Returns this
+// lane's keep mask | mark mask << 16 and whether it is on the list; *vout = its 16 raw bytes.
+__device__ __forceinline__ uint32_t unstuff_masks(const HjdImage &im, const uint8_t *raw, uint32_t lc, UnstuffLds &L, uint4 *vout, bool *listed)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint8_t *base = raw + im.raw_off + (size_t)lc * HJD_UNSTUFF_CHUNK + tid * 16u;
+    const uint4 v = *reinterpret_cast<const uint4 *>(base);
+    *vout = v;
+    L.raw[tid] = v;
+    if (tid == 0) {
+        L.pn[0] = lc == 0 ? 0u : base[-1];
+        L.n = 0u;
+    }
+    if (tid == UNSTUFF_T - 1) L.pn[1] = base[16];
+    __syncthreads();
+    const uint8_t *rb = reinterpret_cast<const uint8_t *>(&L.raw[0]);
+    const uint32_t prev = tid ? rb[tid * 16u - 1u] : L.pn[0];
+    // any 0xFF among the 16 bytes <=> some byte of ~word is zero: (x - 0x01010101) & ~x & 0x80808080 != 0 (exact as an existence test)
+    const uint32_t n0 = ~v.x, n1 = ~v.y, n2 = ~v.z, n3 = ~v.w;
+    const uint32_t anyff = (((n0 - 0x01010101u) & v.x) | ((n1 - 0x01010101u) & v.y) | ((n2 - 0x01010101u) & v.z) | ((n3 - 0x01010101u) & v.w)) & 0x80808080u;
+    const bool slow = anyff != 0u || prev == 0xFFu || lane_nvalid(im, lc, tid) < 16;
+    const unsigned long long bal = __ballot(slow);
+    uint32_t wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&L.n, (uint32_t)__popcll(bal));
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+    if (slow) L.list[wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    __syncthreads();
+    const uint32_t n = L.n;
+    const bool rst = im.restart != 0;
+    for (uint32_t e = tid; e < n; e += UNSTUFF_T) {
+        const uint32_t q = L.list[e];
+        const uint32_t pq = q ? rb[q * 16u - 1u] : L.pn[0];
+        const uint32_t nq = q == UNSTUFF_T - 1 ? L.pn[1] : rb[q * 16u + 16u];
+        uint32_t marks;
+        const uint32_t mask = keepmask_rule(rst, L.raw[q], pq, nq, lane_nvalid(im, lc, q), &marks);
+        L.res[q] = mask | (marks << 16);
+    }
+    __syncthreads();
+    *listed = slow;
+    return slow ? L.res[tid] : 0xFFFFu;
+}
+
+__global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(HjdParams P)
+{
+    __shared__ UnstuffLds L;
     const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
     uint4 v;
-    uint32_t marks;
-    uint32_t mask = unstuff_keepmask(im, P.raw, c - im.chunk0, &v, s_edge, &marks);
-    uint32_t total, mtotal;
-    block_excl_scan(__popc(mask), s_w, &total);
-    block_excl_scan(__popc(marks), s_w, &mtotal);
+    bool listed;
+    const uint32_t mm = unstuff_masks(im, P.raw, c - im.chunk0, L, &v, &listed);
+    uint32_t total; // kept bytes (<= 4096) | markers << 16 (<= 2048)
+    block_excl_scan((uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16), L.w, &total);
     if (threadIdx.x == 0) {
-        P.chunk_kept[c] = total;
-        P.chunk_mark[c] = mtotal;
+        P.chunk_kept[c] = total & 0xFFFFu;
+        P.chunk_mark[c] = total >> 16;
         if (c == im.chunk0) { // a new run of the image starts here: clear what the later kernels accumulate into
             HjdImageState z = {};
             P.st[ii] = z;
@@ -85,38 +133,86 @@ __global__ __launch_bounds__(256) void k_unstuff_count(HjdParams P)
     }
 }
 
-__global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
+__global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
 {
-    __shared__ uint8_t s_edge[512];
-    __shared__ __attribute__((aligned(4))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 8];
-    __shared__ uint32_t s_w[17];
+    __shared__ UnstuffLds L;
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 32]; // the chunk's kept bytes, MSB-first words
+    __shared__ uint32_t s_pos[UNSTUFF_T], s_mk[UNSTUFF_T];
+    const uint32_t tid = threadIdx.x;
     const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
     const uint32_t lc = c - im.chunk0;
+    reinterpret_cast<uint4 *>(s_bytes)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2) reinterpret_cast<uint4 *>(s_bytes)[UNSTUFF_T + tid] = make_uint4(0u, 0u, 0u, 0u);
     // kept bytes and markers of this image's earlier chunks
     uint32_t part = 0, mpart = 0;
-    for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
+    for (uint32_t k = tid; k < lc; k += UNSTUFF_T) {
         part += P.chunk_kept[im.chunk0 + k];
         mpart += P.chunk_mark[im.chunk0 + k];
     }
     uint32_t base, mbase;
-    block_excl_scan(part, s_w, &base);
-    block_excl_scan(mpart, s_w, &mbase);
+    block_excl_scan(part, L.w, &base);
+    block_excl_scan(mpart, L.w, &mbase);
     uint4 v;
-    uint32_t marks;
-    uint32_t mask = unstuff_keepmask(im, P.raw, lc, &v, s_edge, &marks);
-    uint32_t total, mtotal;
-    uint32_t pos = base + block_excl_scan(__popc(mask), s_w, &total);
-    uint32_t mk = mbase + block_excl_scan(__popc(marks), s_w, &mtotal);
+    bool listed;
+    const uint32_t mm = unstuff_masks(im, P.raw, lc, L, &v, &listed);
+    uint32_t tot2;
+    const uint32_t ex = block_excl_scan((uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16), L.w, &tot2);
+    const uint32_t total = tot2 & 0xFFFFu, mtotal = tot2 >> 16;
+    const uint32_t pos0 = base + (ex & 0xFFFFu);
+    const uint32_t mk0 = mbase + (ex >> 16);
     // Transposed stream (see hjd_entropy.hip): word k of subsequence i -> ((i/64)*(wps+2) + k)*64 + i%64,
     // bytes MSB-first inside a word; words 0 and 1 of row i are repeated as words wps, wps+1 of row i-1.
-    // The chunk's kept bytes are first compacted in LDS (byte index ^ 3, so that a 32-bit read yields the
-    // MSB-first word); whole words then go out as 4-byte stores, the up to three bytes of the partial
-    // words at either end of the chunk (shared with the neighbouring chunks) as byte stores.
+    // The chunk's kept bytes are first compacted in LDS as MSB-first words (byte index ^ 3 for byte stores); whole
+    // words then go out as 4-byte stores, the up to three bytes of the partial words at either end of the chunk
+    // (shared with the neighbouring chunks) as byte stores.
     uint8_t *dst = P.ustream + im.ustream_off;
     const uint32_t lw = P.log2_words, wps = 1u << lw;
     const uint32_t wbase = base & ~3u; // stream position of LDS byte 0
+    if (!listed) {
+        // all 16 bytes stay: as four MSB-first words, shifted to the destination's byte phase, OR-ed into the zeroed
+        // buffer (neighbouring lanes own the other bytes of the two partial words)
+        const uint32_t a = pos0 - wbase, sh = (a & 3u) * 8u, q = a >> 2;
+        const uint32_t b0 = __builtin_bswap32(v.x), b1 = __builtin_bswap32(v.y), b2 = __builtin_bswap32(v.z), b3 = __builtin_bswap32(v.w);
+        uint32_t *sw = reinterpret_cast<uint32_t *>(s_bytes) + q;
+        atomicOr(&sw[0], __builtin_amdgcn_alignbit(0u, b0, sh));
+        atomicOr(&sw[1], __builtin_amdgcn_alignbit(b0, b1, sh));
+        atomicOr(&sw[2], __builtin_amdgcn_alignbit(b1, b2, sh));
+        atomicOr(&sw[3], __builtin_amdgcn_alignbit(b2, b3, sh));
+        if (sh) atomicOr(&sw[4], b3 << (32u - sh));
+    } else {
+        s_pos[tid] = pos0;
+        s_mk[tid] = mk0;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < L.n; e += UNSTUFF_T) { // listed lanes, densely: byte by byte
+        const uint32_t q = L.list[e];
+        const uint32_t m2 = L.res[q], mask = m2 & 0xFFFFu, marks = m2 >> 16;
+        const uint4 vq = L.raw[q];
+        const uint32_t words[4] = {vq.x, vq.y, vq.z, vq.w};
+        uint32_t pos = s_pos[q], mk = s_mk[q];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint8_t bv = (uint8_t)(words[j >> 2] >> ((j & 3) * 8));
+            if (marks & (1u << j)) { // a marker sits between kept byte pos-1 and pos
+                if (mk < im.mark_cap) {
+                    P.mpos[im.mark_off + mk] = pos * 8u;
+                    P.mval[im.mark_off + mk] = bv;
+                }
+                // anything but RSTn between the intervals: the reference would take it for a resync point too,
+                // with results no standard stream defines (what follows the last interval — EOI, padding —
+                // is never looked at again)
+                if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7) && !im.conformant) atomicOr(&P.st[ii].flags, HJD_FLAG_BAD_MARKER);
+                mk++;
+            }
+            if (mask & (1u << j)) {
+                s_bytes[(pos - wbase) ^ 3u] = bv;
+                pos++;
+            }
+        }
+    }
+    __syncthreads();
     auto put_word_or_byte = [&](uint32_t wq, uint32_t value, int bsel) {
         const uint32_t i = wq >> lw, k = wq & (wps - 1u);
         const size_t a0 = (((size_t)(i >> 6) * (wps + 2u) + k) * 64u + (i & 63u)) * 4u;
@@ -129,42 +225,21 @@ __global__ __launch_bounds__(256) void k_unstuff_write(HjdParams P)
             else dst[a1 + (uint32_t)bsel] = (uint8_t)value;
         }
     };
-    uint32_t words[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint8_t bv = (uint8_t)(words[j >> 2] >> ((j & 3) * 8));
-        if (marks & (1u << j)) { // a marker sits between kept byte pos-1 and pos
-            if (mk < im.mark_cap) {
-                P.mpos[im.mark_off + mk] = pos * 8u;
-                P.mval[im.mark_off + mk] = bv;
-            }
-            // anything but RSTn between the intervals: the reference would take it for a resync point too,
-            // with results no standard stream defines (what follows the last interval — EOI, padding —
-            // is never looked at again)
-            if (mk < im.n_rst && !(bv >= 0xD0 && bv <= 0xD7) && !im.conformant) atomicOr(&P.st[ii].flags, HJD_FLAG_BAD_MARKER);
-            mk++;
-        }
-        if (mask & (1u << j)) {
-            s_bytes[(pos - wbase) ^ 3u] = bv;
-            pos++;
-        }
-    }
-    __syncthreads();
     {
         const uint32_t endp = base + total;                 // one past the chunk's last kept byte
         const uint32_t w_first = (base + 3u) >> 2, w_last = endp >> 2; // whole words [w_first, w_last)
-        for (uint32_t wq = w_first + threadIdx.x; wq < w_last; wq += blockDim.x)
+        for (uint32_t wq = w_first + tid; wq < w_last; wq += UNSTUFF_T)
             put_word_or_byte(wq, *reinterpret_cast<const uint32_t *>(&s_bytes[(wq << 2) - wbase]), -1);
         // bytes of the partial words: head = [base, min(4*w_first, endp)), tail = [4*w_last, endp) when w_last >= w_first
-        if (threadIdx.x < 4) {
-            const uint32_t q = base + threadIdx.x;
+        if (tid < 4) {
+            const uint32_t q = base + tid;
             if (q < min(w_first << 2, endp)) put_word_or_byte(q >> 2, s_bytes[(q - wbase) ^ 3u], (int)(3u - (q & 3u)));
-        } else if (threadIdx.x < 8 && w_last >= w_first) {
-            const uint32_t q = (w_last << 2) + (threadIdx.x - 4);
+        } else if (tid < 8 && w_last >= w_first) {
+            const uint32_t q = (w_last << 2) + (tid - 4);
             if (q < endp) put_word_or_byte(q >> 2, s_bytes[(q - wbase) ^ 3u], (int)(3u - (q & 3u)));
         }
     }
-    if (lc == im.nchunks - 1 && threadIdx.x == 0) {
+    if (lc == im.nchunks - 1 && tid == 0) {
         P.st[ii].ustream_len = base + total;
         P.st[ii].nmarkers = mbase + mtotal;
     }
