@@ -42,7 +42,16 @@ __constant__ uint8_t c_zz_to_slot[64] = HJD_ZZ_TO_SLOT;
 struct EntropyLds {
     const uint16_t *lut; // [nlut][HJD_LUT_SIZE]
     const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
+    const uint2 *mt;     // [nb] block-in-MCU m -> (byte offsets DC | AC << 16 of its tables, next m): the block-end step is
+                         // taken by some lane of a wave in nearly every iteration, so it is two LDS reads instead of nine VALU
 };
+
+// fills EntropyLds::mt (first nb lanes; the caller synchronises)
+__device__ __forceinline__ void fill_mcu_table(uint2 *mt, uint32_t nb, uint32_t nby, uint32_t tabY, uint32_t tabCb, uint32_t tabCr)
+{
+    const uint32_t m = threadIdx.x;
+    if (m < nb) mt[m] = make_uint2(m < nby ? tabY : (m == nby ? tabCb : tabCr), m + 1u == nb ? 0u : m + 1u);
+}
 
 // address of word 0 of subsequence (row) i in the transposed stream; successive words are 64 words apart
 __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t i, uint32_t lw)
@@ -170,6 +179,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
         mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
     }
     uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
+    uint32_t mnx = (m + 1u == nb) ? 0u : m + 1u;
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
@@ -248,8 +258,10 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             if (WRITE) write_block_entry(W, nblk);
             nblk++;
             if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
-            m = (m + 1u == nb) ? 0u : m + 1u;
-            pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
+            m = mnx;
+            const uint2 t = L.mt[m];
+            pair = t.x;
+            mnx = t.y;
             tb = pair & 0xFFFFu;
         }
         const uint32_t tot = len + s;
@@ -269,6 +281,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 z = 0u;
                 m = 0u;
                 pair = tabY;
+                mnx = L.mt[0].y;
                 tb = pair & 0xFFFFu;
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
@@ -287,6 +300,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 z = 0u;
                 m = 0u;
                 pair = tabY;
+                mnx = L.mt[0].y;
                 tb = pair & 0xFFFFu;
                 rc.left = rc.ri_blocks;
                 rc.mk++;
@@ -393,16 +407,18 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     uint32_t *s_lp = s_cnt + T;   // work list: start bit position ...
     uint32_t *s_lzm = s_lp + T;   // ... start z | m << 8 | slot << 16
     uint32_t *s_wc = s_lzm + T;   // dirty subsequences per wave
-    uint32_t *s_rows = s_wc + 16;
+    uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 16);
+    uint32_t *s_rows = s_wc + 32;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     RowEnv E;
     E.P = &P;
     E.im = &im;
-    E.L = {s_lut, s_sec};
+    E.L = {s_lut, s_sec, s_mt};
     E.tabY = table_pair(ts->slot_pack, 0, 4u);
     E.tabCb = table_pair(ts->slot_pack, 1, 4u);
     E.tabCr = table_pair(ts->slot_pack, 2, 4u);
+    fill_mcu_table(s_mt, im.nb, im.nby, E.tabY, E.tabCb, E.tabCr);
     E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
     E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
     E.total_bits = total_bits;
@@ -575,7 +591,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word);
     uint32_t *s_w = s_dyn + P.lds_state_word;
     uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
-    uint32_t *s_rows = s_w + 48;
+    uint2 *s_mt = reinterpret_cast<uint2 *>(s_w + 48);
+    uint32_t *s_rows = s_w + 64;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits;
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     if (wg * HJD_WRITE_WG >= nsub) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
+    fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
 
     const uint32_t i = wg * HJD_WRITE_WG + tid;
     const bool valid = i < nsub;
@@ -611,7 +629,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     RowEnv E;
     E.P = &P;
     E.im = &im;
-    E.L = {s_lut, s_sec};
+    E.L = {s_lut, s_sec, s_mt};
     E.tabY = table_pair(ts->slot_pack, 0, 2u);
     E.tabCb = table_pair(ts->slot_pack, 1, 2u);
     E.tabCr = table_pair(ts->slot_pack, 2, 2u);

@@ -555,8 +555,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + 16 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
-        P.lds_bytes_write = (P.lds_state_word + 48 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_write = (P.lds_state_word + 64 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
 
