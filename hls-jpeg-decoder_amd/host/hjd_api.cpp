@@ -56,6 +56,8 @@ struct DeviceGuard {
 struct hjd_decoder {
     int device = 0;
     uint32_t subseq_bits = 2048;
+    bool subseq_auto = true;    // no explicit size: chosen per batch from the amount of scan data (batch_build)
+    bool overlap_auto = true;
     int sync_launches = 2; // one synchronisation launch + one repair launch (a gate that returns at once unless a
                            // workgroup's 16 kbit of warm-up were not enough; whatever it leaves is caught by
                            // k_write's induction check and repaired from the host)
@@ -293,6 +295,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
                 return nullptr;
             }
             d->subseq_bits = (uint32_t)opt->subseq_bits;
+            d->subseq_auto = false;
         }
         if (opt->sync_launches > 0) d->sync_launches = opt->sync_launches;
         if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
@@ -300,13 +303,19 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->conformant = opt->conformant ? 1 : 0;
     }
     const char *e = getenv("HJD_SUBSEQ_BITS");
-    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) d->subseq_bits = (uint32_t)atoi(e);
+    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) {
+        d->subseq_bits = (uint32_t)atoi(e);
+        d->subseq_auto = false;
+    }
     {   // warm-up: ~16384 bits of look-back, which a wrong start state does not survive in practice (measured
         // survival on the q85 bench content: 30 % after 1024 bits, 8 % after 2048, about x0.27 per further 1024)
         uint32_t k = 16384 / d->subseq_bits;
         d->sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
         const char *ek = getenv("HJD_SYNC_OVERLAP");
-        if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) d->sync_overlap = (uint32_t)atoi(ek);
+        if (ek && atoi(ek) >= 0 && atoi(ek) <= 48) {
+            d->sync_overlap = (uint32_t)atoi(ek);
+            d->overlap_auto = false;
+        }
         const char *ep = getenv("HJD_PHASE_WORDS"); // tuning knob: staging window in 32-bit words (power of two)
         if (ep && atoi(ep) >= 2 && atoi(ep) <= 64 && (atoi(ep) & (atoi(ep) - 1)) == 0) d->phase_words = (uint32_t)atoi(ep);
         if (opt && opt->sync_overlap != 0) {
@@ -316,6 +325,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
                 return nullptr;
             }
             d->sync_overlap = opt->sync_overlap < 0 ? 0u : (uint32_t)opt->sync_overlap;
+            d->overlap_auto = false;
         }
     }
     return d;
@@ -414,12 +424,27 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->dirty_decodes = 0;
     DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
-    const uint32_t S = d->subseq_bits;
+    // Subsequence size: every lane of the entropy kernels decodes one subsequence serially, so a small batch wants short
+    // ones (one 4K image: 0.43 ms at 256 bits against 0.65 ms at 2048) and a large batch long ones (fewer wasted
+    // synchronisation decodes: 16 x 4K, 2048 bits).  Unless the caller fixed it: the largest power of two that still
+    // leaves about 65536 subsequences (256 CUs x 256 lanes of the final pass), within 256..2048.
+    uint32_t S = d->subseq_bits, K = d->sync_overlap;
+    if (d->subseq_auto) {
+        uint64_t bits = 0;
+        for (int i = 0; i < b->n; i++)
+            if (b->parse_status[i] == HJD_OK) bits += (uint64_t)parsed[i].stream_len * 8u;
+        S = 256;
+        while (S < 2048 && (uint64_t)S * 2u * 65536u <= bits) S *= 2;
+        if (d->overlap_auto) {
+            const uint32_t k = 16384 / S;
+            K = k < 4 ? 4 : (k > 32 ? 32 : k);
+        }
+    }
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, blk_cur = 0, rec_cur = 0, out_cur = 0;
     uint32_t max_nlut = 1, max_nsec = 0;
-    const uint32_t K = d->sync_overlap, Q = HJD_SYNC_WG - K; // owned subsequences per synchronisation workgroup
+    const uint32_t Q = HJD_SYNC_WG - K; // owned subsequences per synchronisation workgroup
 
     for (int i = 0; i < b->n; i++) {
         b->dev_index[i] = -1;
@@ -753,6 +778,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     if (!j || !o) return HJD_ERR_ARG;
     hjd_decoder d; // never touches a device
     if (subseq_bits) d.subseq_bits = (uint32_t)subseq_bits;
+    d.subseq_auto = d.overlap_auto = false; // the layout of exactly this size (0 = 2048)
     {
         uint32_t k = 16384 / d.subseq_bits;
         d.sync_overlap = k < 4 ? 4 : (k > 32 ? 32 : k);
@@ -771,8 +797,8 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     if (b.parse_status[0] != HJD_OK || b.img.empty()) return b.parse_status[0] ? b.parse_status[0] : HJD_ERR_UNSUPPORTED;
     const HjdImage &im = b.img[0];
     memset(o, 0, sizeof(*o));
-    o->subseq_bits = d.subseq_bits;
-    o->sync_overlap = d.sync_overlap;
+    o->subseq_bits = b.P.subseq_bits;
+    o->sync_overlap = b.P.sync_overlap;
     o->phase_words = b.P.phase_words;
     o->sync_wg = HJD_SYNC_WG;
     o->write_wg = HJD_WRITE_WG;
@@ -1171,7 +1197,7 @@ extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)
     stats4[0] = st.sync_iters;
     stats4[1] = st.sync_decodes;
     stats4[2] = st.sync_iters_max;
-    stats4[3] = (uint32_t)(((uint64_t)st.ustream_len * 8 + b->dec->subseq_bits - 1) / b->dec->subseq_bits);
+    stats4[3] = (uint32_t)(((uint64_t)st.ustream_len * 8 + b->P.subseq_bits - 1) / b->P.subseq_bits);
     (void)im;
     return HJD_OK;
 }

@@ -112,7 +112,7 @@ typedef enum hjd_out_format {
 } hjd_out_format;
 
 typedef struct hjd_options {
-    int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..4096); 0 = default (2048) */
+    int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..4096); 0 = chosen per batch from its scan bytes (256..2048) */
     int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
     int streams;         /* internal HIP streams a batch is split over (contiguous image ranges, forked from and
                           * joined to the caller's stream); 0 or 1 = everything on the caller's stream */
