@@ -200,7 +200,7 @@ def main():
 
     if args.internal_streams > 1:
         args.streams = 1
-    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=args.internal_streams)
+    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=max(1, args.internal_streams))  # 1 = no split inside the library
     # parse + H2D: inputs are resident in HBM from here on.  The per-GPU share may be split into
     # sub-batches that run on separate HIP streams, so that one sub-batch's latency-bound
     # synchronisation tail overlaps another's IDCT (same total work per step).

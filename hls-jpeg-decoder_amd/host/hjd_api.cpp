@@ -63,7 +63,7 @@ struct hjd_decoder {
                            // k_write's induction check and repaired from the host)
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
-    int streams = 1;           // internal HIP streams a batch is split over (hjd_options.streams)
+    int streams = 0;           // image ranges a batch is split into (hjd_options.streams); 0 = by batch size
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
     int conformant = 0;        // hjd_options.conformant: opt-in, outside the parity contract
     // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
@@ -395,8 +395,10 @@ static void batch_free_device(hjd_batch *b)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
         for (auto &e : v) (void)hipEventDestroy(e);
-    for (auto &st : b->istreams) (void)hipStreamDestroy(st);
-    for (auto &e : b->join_ev) (void)hipEventDestroy(e);
+    for (auto &st : b->istreams)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto &e : b->join_ev)
+        if (e) (void)hipEventDestroy(e);
     if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
 }
 
@@ -698,11 +700,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.nimg = b->nimg;
     P.off_chunk = P.off_syncwg = P.off_repwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
     {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
-        int ns = d->streams;
-        if (ns > b->nimg) ns = b->nimg;
-        if (ns < 1) ns = 1;
         uint64_t total_px = 0;
         for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
+        int ns = d->streams;
+        if (ns == 0) // measured on 4K images, one caller stream: 8..32 images +4 % with two ranges, 64 images +17 % with three
+            ns = total_px >= 400000000ull ? 3 : (total_px >= 60000000ull ? 2 : 1);
+        if (ns > b->nimg) ns = b->nimg;
+        if (ns < 1) ns = 1;
         int i0 = 0;
         uint64_t acc = 0;
         for (int k = 0; k < ns; k++) {
@@ -730,11 +734,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         }
         if (b->ranges.size() > 1) {
             while (b->istreams.size() < b->ranges.size()) {
-                hipStream_t st;
-                hipEvent_t e;
-                HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                hipStream_t st = nullptr; // entry 0 stays empty: range 0 runs on the caller's stream
+                hipEvent_t e = nullptr;
+                if (!b->istreams.empty()) {
+                    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
                 b->istreams.push_back(st);
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 b->join_ev.push_back(e);
             }
             if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
@@ -949,14 +955,20 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.nblk = b->nblk_entries;
         return range_enqueue(b, all, s, from_resync, nstage, names, evs);
     }
+    // range 0 stays on the caller's stream, the others fork off it: n ranges occupy n hardware queues, not n + 1 (a
+    // process has four by default; a fifth stream shares one and serialises behind it)
     HIPCHK(hipEventRecord(b->fork_ev, s));
-    for (size_t k = 0; k < b->ranges.size(); k++) {
+    for (size_t k = 1; k < b->ranges.size(); k++) {
         HIPCHK(hipStreamWaitEvent(b->istreams[k], b->fork_ev, 0));
         int rc = range_enqueue(b, b->ranges[k], b->istreams[k], from_resync, nullptr, nullptr, nullptr);
         if (rc) return rc;
         HIPCHK(hipEventRecord(b->join_ev[k], b->istreams[k]));
-        HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
     }
+    {
+        int rc = range_enqueue(b, b->ranges[0], s, from_resync, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    for (size_t k = 1; k < b->ranges.size(); k++) HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
     return HJD_OK;
 }
 

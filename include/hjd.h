@@ -114,8 +114,9 @@ typedef enum hjd_out_format {
 typedef struct hjd_options {
     int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..4096); 0 = chosen per batch from its scan bytes (256..2048) */
     int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
-    int streams;         /* internal HIP streams a batch is split over (contiguous image ranges, forked from and
-                          * joined to the caller's stream); 0 or 1 = everything on the caller's stream */
+    int streams;         /* image ranges a batch is split into, each on its own HIP stream (the first on the caller's; the
+                          * others forked from and joined to it): one range's latency-bound synchronisation then overlaps
+                          * another's IDCT.  0 = by batch size (1 below 60 Mpixel, 2 up to 400, 3 above), 1 = no split */
     int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
                           * 0 = default (8192 bits' worth), -1 = none, 1..48 = that many.  Too little warm-up is
                           * never wrong, only slower: hjd_batch_finish then re-synchronises from the host. */

@@ -11,7 +11,7 @@ import hjdtools as T
 
 hjd = importlib.import_module("hls-jpeg-decoder_amd")
 jpgs = [T.synth_jpeg(3840, 2160, 1000 + s, 85, 2, 2) for s in range(8)] * 2
-dec = hjd.Decoder(0)
+dec = hjd.Decoder(0, streams=1)  # one launch of 16 images per kernel
 b = dec.prepare(jpgs)
 for _ in range(3):
     b.run()
