@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     }
     uint32_t mycomp = 0;
     if (tid < KB) {
-        const uint32_t mm = tid % nb;
+        // tid % nb without a division: nb is 3, 4 or 6 (hf*vf <= 4) and tid < 256, where floor(tid/nb) == tid * ceil(2^16/nb) >> 16
+        const uint32_t inv = nb == 4u ? 16384u : (nb == 3u ? 21846u : 10923u);
+        const uint32_t mm = tid - ((tid * inv) >> 16) * nb;
         mycomp = mm < nby ? 0u : mm - nby + 1u;
         s_comp[tid] = (uint8_t)mycomp;
         s_mask[tid][0] = be.z & ~1u;

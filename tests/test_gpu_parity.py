@@ -654,3 +654,32 @@ def test_conformant_mode_takes_16_bit_dc_codes(hjd, dec, golden):
     st, outs = conf.decode([data, open(os.path.join(d, "syn_250x187_420_q85.jpg"), "rb").read()])
     conf.close()
     assert st == [0, 0] and np.array_equal(outs[0], outs[1])
+
+
+def test_byte_stuffing_dense_streams(hjd, dec):
+    """Noise at high quality: an 0xFF (hence a stuffed 0x00, or with DRI a marker) in about every tenth 16-byte lane of the unstuff
+    kernels; FF as the last byte of a lane / of a 4 KiB chunk, stuffed zeros as the first.  The unstuff kernels treat lanes without
+    an FF wholesale and work the others off a list: every decision of that split is exercised here, in one batch whose images
+    start at unrelated chunk phases, and checked against the oracle."""
+    rng = np.random.default_rng(5)
+    jpgs = []
+    for k, (w, h, hf, vf, rst) in enumerate([(257, 131, 1, 1, 0), (640, 360, 2, 2, 0), (333, 222, 2, 1, 0), (512, 96, 1, 1, 3),
+                                            (640, 368, 2, 2, 40), (97, 411, 1, 2, 0), (48, 48, 1, 1, 0), (1024, 512, 2, 2, 0)]):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        jpgs.append(T.encode_jpeg(rgb, 98 if k % 2 == 0 else 92, hf, vf, rst))
+    assert sum(j.count(b"\xff\x00") for j in jpgs) > 4000
+    # stuffed pairs at every phase of a 16-byte lane, including split across two lanes (FF last, 00 first)
+    phases = set()
+    for j in jpgs:
+        sos = j.index(b"\xff\xda")
+        scan0 = sos + 2 + int.from_bytes(j[sos + 2:sos + 4], "big")
+        q = j.find(b"\xff\x00", scan0)
+        while q >= 0:
+            phases.add((q - scan0) % 16)
+            q = j.find(b"\xff\x00", q + 2)
+    assert phases == set(range(16))
+    st, outs = dec.decode(jpgs)
+    assert st == [0] * len(jpgs), st
+    for k, j in enumerate(jpgs):
+        orc, orgb, _, _, _ = T.oracle_decode(j)
+        assert orc == 0 and np.array_equal(outs[k], orgb), k
