@@ -683,3 +683,37 @@ def test_byte_stuffing_dense_streams(hjd, dec):
     for k, j in enumerate(jpgs):
         orc, orgb, _, _, _ = T.oracle_decode(j)
         assert orc == 0 and np.array_equal(outs[k], orgb), k
+
+
+def test_random_corpus(hjd, dec):
+    """Property test over the parameter space the parser admits: 240 seeded random images (1..400 pixels a side, every
+    sampling with hf*vf <= 4, quality 15..100, smooth to noisy content, no / short / long restart intervals, two or three
+    DQTs, standard / permuted / optimised Huffman tables), decoded in three batches (ragged mixes of table sets and sizes).
+    Wherever the oracle — the reference's algorithm — produces an image the HIP path must produce the same bytes; where
+    the reference would not terminate or overrun, it must report an error."""
+    rng = np.random.default_rng(20251004)
+    samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4)]
+    jpgs = []
+    for k in range(240):
+        w, h = int(rng.integers(1, 401)), int(rng.integers(1, 401))
+        hf, vf = samplings[int(rng.integers(0, len(samplings)))]
+        q = int(rng.integers(15, 101))
+        sigma = float(rng.choice([0.0, 0.5, 3.0, 8.0, 30.0]))
+        nm = -(-w // (8 * hf)) * -(-h // (8 * vf))
+        rst = int(rng.choice([0, 0, 1, int(rng.integers(1, nm + 2)), -(-w // (8 * hf))]))
+        rgb = T.synth_rgb(w, h, 9000 + k, sigma)
+        jpgs.append(T.encode_jpeg_ex(rgb, q, hf, vf, rst, three_dqt=bool(rng.integers(0, 2)),
+                                     huff_mode=int(rng.choice([T.HUFF_STD, T.HUFF_SIX_PERMUTED, T.HUFF_SIX_OPTIMISED, T.HUFF_FOUR_OPTIMISED]))))
+    ok = bad = 0
+    for lo in range(0, len(jpgs), 80):
+        part = jpgs[lo:lo + 80]
+        st, outs = dec.decode(part)
+        for k, j in enumerate(part):
+            orc, orgb, _, _, _ = T.oracle_decode(j)
+            if orc == 0:
+                assert st[k] == 0 and np.array_equal(outs[k], orgb), (lo + k, st[k])
+                ok += 1
+            else:
+                assert st[k] != 0, (lo + k, orc)
+                bad += 1
+    assert ok >= 180 and bad >= 10, (ok, bad)
