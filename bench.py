@@ -149,6 +149,7 @@ def main():
                     help="instead: ONE batch, split inside the library (hjd_options.streams); no per-stage timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true", help="diagnostic: no hipEvents between the kernels of the timed steps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -231,7 +232,7 @@ def main():
         st = b.finish(sh)
         assert all(s == 0 for s in st), st
 
-    if args.internal_streams <= 1:
+    if args.internal_streams <= 1 and not args.no_stage_events:
         for b in batches:
             b.enable_timing(args.steps)
     barrier()
