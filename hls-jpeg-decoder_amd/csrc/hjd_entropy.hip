@@ -193,15 +193,12 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             // synchronisation form: [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The
             // pair is taken while the first symbol cannot end the block (an AC advance is at most 16) and the second
             // still starts inside the subsequence (a step is at most 31 bits): the states passed on are then exactly
-            // those of the symbol-by-symbol walk of the final pass.  Restart streams keep to single steps (the marker
-            // rules look at every symbol boundary).
+            // those of the symbol-by-symbol walk of the final pass.
             const uint16_t *ep = reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
-            const uint32_t e1 = ep[0];
-            e = e1;
-            if (!RESTART) {
-                const uint32_t e2 = ep[1];
-                e = (z < 48u && p < pair_lim) ? e2 : e1;
-            }
+            const uint32_t e1 = ep[0], e2 = ep[1];
+            // restart streams: only while the next marker is more than a step (31 bits) plus the 8 bits of the rules' look-ahead
+            // away, so that no marker rule could have fired at the boundary the pair steps over
+            e = (z < 48u && p < pair_lim && (!RESTART || p + 40u < mnext)) ? e2 : e1;
         }
         if ((e & 31u) == 0u) {
             // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
