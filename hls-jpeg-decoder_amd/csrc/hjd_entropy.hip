@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "hjd_device.h"
 #include "hjd_kernels.h"
 #include "hjd_kutil.h"
@@ -675,11 +677,21 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 
 // ---- launch wrappers --------------------------------------------------------------------------
 
-static int set_dyn_lds(const void *fn, uint32_t bytes)
+// Dynamic LDS above 32 KB needs the function attribute raised once per (kernel, device) — not on every launch
+// (round 2 paid a hipFuncSetAttribute per launch, 36 per bench step).  `which` = 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_write.
+static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
 {
-    if (bytes > 32768 &&
-        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-        return -1;
+    static std::atomic<uint32_t> granted[4][16];
+    if (bytes <= 32768) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
+    const bool cached = dev < 16;
+    if (cached && granted[which][dev].load(std::memory_order_relaxed) >= bytes) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    if (cached) { // keep the maximum: concurrent callers may raise it in either order
+        uint32_t cur = granted[which][dev].load(std::memory_order_relaxed);
+        while (cur < bytes && !granted[which][dev].compare_exchange_weak(cur, bytes)) {}
+    }
     return 0;
 }
 
@@ -687,13 +699,13 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
 {
     if (!nwg) return 0;
     if (mode == 0) {
-        if (set_dyn_lds(reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
+        if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     } else if (mode == 1) {
-        if (set_dyn_lds(reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
+        if (set_dyn_lds(1, reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     } else {
-        if (set_dyn_lds(reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
+        if (set_dyn_lds(2, reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     }
     hipError_t e_ = hipGetLastError();
@@ -711,7 +723,7 @@ int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s)
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
 {
     if (!nwg) return 0;
-    if (set_dyn_lds(reinterpret_cast<const void *>(k_write), P.lds_bytes_write)) return -1;
+    if (set_dyn_lds(3, reinterpret_cast<const void *>(k_write), P.lds_bytes_write)) return -1;
     hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_WRITE_WG), P.lds_bytes_write, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;

@@ -290,11 +290,13 @@ __global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
     // (short)(int) cast.
     {
         const uint32_t *rec = P.rec + im.rec_off;
-        // a group holds at most 63 records per block plus the padding at subsequence ends; entries left over
-        // from a run that failed half-way (the image then carries an error status) must not turn this loop
-        // into a walk over the whole record array
+        // A group holds at most 63 records per block, and every subsequence's run with k >= 1 of them inside the group
+        // is padded to at most k + 3 <= 4k entries: 4 * 63 * KB bounds the span of any real group (round 2 capped it at
+        // MAXGB * 64 + 1024, which dense q100 content exceeds at 64-bit subsequences: records dropped without a
+        // status).  Entries left over from a run that failed half-way (the image then carries an error status) still
+        // cannot turn this loop into a walk over the whole record array.
         const uint32_t r0 = s_range[0];
-        const uint32_t r1 = min(s_range[1], r0 + MAXGB * 64u + 1024u);
+        const uint32_t r1 = min(s_range[1], r0 + 4u * 63u * KB + 4u);
         const uint32_t b0 = (uint32_t)(gm.y - im.blk_off);
         for (uint32_t t = (r0 & ~3u) + tid * 4u; t < r1; t += 1024u) {
             const uint4 q = *reinterpret_cast<const uint4 *>(rec + t);

@@ -1314,11 +1314,8 @@ extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const
         std::vector<int> pst(sl.count, 0);
         rc = hjd_batch_reset(sl.b, sl.count, jpg + i0, jpg_len + i0, out_format, pst.data(), d->s_up);
         if (rc != HJD_OK) break;
-        HIPCHK(hipEventRecord(sl.up_done, d->s_up));
-        HIPCHK(hipStreamWaitEvent(d->s_run, sl.up_done, 0));
-        if ((rc = hjd_batch_run(sl.b, d->s_run)) != HJD_OK) break;
-        HIPCHK(hipEventRecord(sl.run_done, d->s_run));
-        HIPCHK(hipStreamWaitEvent(d->s_down, sl.run_done, 0));
+        // the caller's output buffers are checked BEFORE anything of this chunk is enqueued on the run stream: an error
+        // return must not leave kernels in flight that the next call's hjd_batch_reset would rewrite the inputs of
         sl.direct.assign(sl.count, 0);
         size_t stage_need = 0;
         for (int k = 0; k < sl.count; k++) {
@@ -1332,6 +1329,11 @@ extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const
             if (!sl.direct[k] && off + nb > stage_need) stage_need = off + nb;
         }
         if (rc != HJD_OK) break;
+        HIPCHK(hipEventRecord(sl.up_done, d->s_up));
+        HIPCHK(hipStreamWaitEvent(d->s_run, sl.up_done, 0));
+        if ((rc = hjd_batch_run(sl.b, d->s_run)) != HJD_OK) break;
+        HIPCHK(hipEventRecord(sl.run_done, d->s_run));
+        HIPCHK(hipStreamWaitEvent(d->s_down, sl.run_done, 0));
         if (stage_need > sl.h_out_cap) {
             if (sl.h_out) (void)hipHostFree(sl.h_out);
             sl.h_out = nullptr;
@@ -1352,6 +1354,11 @@ extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const
     for (auto &sl : d->slot) {
         const int r = pipe_retire(d, sl, out, out_cap, status);
         if (rc == HJD_OK) rc = r;
+    }
+    if (rc != HJD_OK) { // error exit: nothing of this call may still be in flight when the ring is used again
+        (void)hipStreamSynchronize(d->s_up);
+        (void)hipStreamSynchronize(d->s_run);
+        (void)hipStreamSynchronize(d->s_down);
     }
     return rc;
 }

@@ -184,6 +184,25 @@ def test_subsequence_sizes(hjd, bits, golden):
     d.close()
 
 
+@pytest.mark.parametrize("bits", [64, 128, 256])
+def test_dense_records_at_small_subsequences(hjd, bits):
+    """Uniform noise at q100, 4:2:0: nearly every coefficient of every block is non-zero, and with 64-bit subsequences
+    every run of a few records is padded to a whole burst, so that a 96-block IDCT group spans close to 8000 record
+    entries (round 2 capped the walk at 7168 and silently dropped the rest)."""
+    rng = np.random.default_rng(77)
+    d = hjd.Decoder(0, subseq_bits=bits)
+    jpgs = []
+    for w, h in ((1024, 16), (272, 48)):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        jpgs.append(T.encode_jpeg(rgb, 100, 2, 2))
+    st, outs = d.decode(jpgs)
+    assert st == [0, 0]
+    for j, o in zip(jpgs, outs):
+        rc, orgb, _, _, _ = T.oracle_decode(j)
+        assert rc == 0 and np.array_equal(o, orgb), bits
+    d.close()
+
+
 def test_restart_fixtures(hjd, dec, golden):
     """Committed restart-marker fixtures: the output equals the compiled reference's — inside the clean-resync
     domain through the parallel path, and for the dirty one (the reference fires its resync early on tiny blocks,
@@ -219,12 +238,22 @@ def test_restart_fixtures(hjd, dec, golden):
     (256, 256, 2, 2, 5, 0.5),     # smooth content: tiny trailing blocks are likely
     (256, 256, 1, 1, 1, 0.0),     # flat-ish 4:4:4, 1-MCU intervals: dirty in practice
     (128, 128, 2, 2, 0xFFFF, 6.0),  # DRI present, interval longer than the image: no RSTn at all
+    (320, 240, 2, 2, -1, 6.0),    # DRI segment with Ri = 0: the reference keys its resync checks on the segment LENGTH
+    (200, 120, 1, 1, -1, 0.5),    # (openjpg.cpp:441-446), so they are live although the scan holds no RSTn; smooth content:
+    (64, 64, 2, 1, -1, 0.0),      # the last blocks are short and the reference's cursor reaches EOI early
 ])
 def test_restart_synthetic_matches_oracle_or_is_refused(hjd, dec, w, h, hf, vf, rst, sigma):
     """Mixed subsampling + restart intervals (BASELINE config 5).  The oracle emulates the reference's
     resync rules exactly; whenever the reference decodes the stream — inside the clean-resync domain or not — the
     HIP path must be bit-exact, and where the reference cannot (it would hang / overrun) it must report an error."""
-    data = T.synth_jpeg(w, h, 77 + rst % 50, 85, hf, vf, rst, sigma)
+    if rst < 0:
+        data = T.synth_jpeg(w, h, 77, 85, hf, vf, 0, sigma)
+        sos = data.index(b"\xff\xda")
+        data = data[:sos] + b"\xff\xdd\x00\x04\x00\x00" + data[sos:]
+        rc, jd = hjd.parse_header(data)
+        assert rc == 0 and jd.restart_interval > 0 and jd.restart_mcus == 0
+    else:
+        data = T.synth_jpeg(w, h, 77 + rst % 50, 85, hf, vf, rst, sigma)
     orc, orgb, _, _, ost = T.oracle_decode(data)
     st, outs = dec.decode([data])
     if orc == 0:
@@ -502,9 +531,14 @@ def test_two_ranks_share_one_batch(hjd, tmp_path):
             assert got[str(g)].startswith("status"), g
 
 
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks itself; here both on device 0
-    over gloo (rehearsal knobs).  The line must say n_gpus 2 and count both ranks' pixels."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_launches_its_own_ranks(tmp_path, world):
+    """`python bench.py --gpus N` without a launcher: the parent spawns the ranks itself; here all on device 0
+    over gloo (rehearsal knobs), with BASELINE config 4's image shape (1080p 4:2:0 q85).  N = 4 is the largest world size this
+    pool allows on one card (at most 6 processes may use it, this test process being one); the 8-rank plumbing is covered
+    without a GPU by tests/test_shard_gloo.py::test_eight_rank_rehearsal_of_config4_plumbing.  The line must say n_gpus N,
+    count every rank's pixels, and every rank checks its own outputs against reference hashes / the oracle (bench.py exits
+    non-zero on a mismatch, and the parent on any rank's failure)."""
     import json
     import subprocess
     import sys
@@ -512,13 +546,14 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env = dict(os.environ, HJD_BENCH_BACKEND="gloo", HJD_BENCH_FORCE_DEVICE="0")
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                         "--batch", "8", "--width", "1920", "--height", "1080", "--distinct", "2", "--streams", "2",
                         "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["config"]["images_per_gpu"] == 8
-    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - 16 * 1920 * 1080) / (16 * 1920 * 1080) < 0.02
+    assert line["n_gpus"] == world and line["config"]["images_per_gpu"] == 8 and line["parity"] == "ok"
+    px = 8 * world * 1920 * 1080
+    assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - px) / px < 0.02
 
 
 def test_empty_and_all_bad_batches(hjd, dec):

@@ -92,3 +92,49 @@ def test_bench_parent_spawns_ranks_and_reports_failure():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def _bench_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_eight_rank_rehearsal_of_config4_plumbing():
+    """BASELINE config 4 is 8 ranks.  This pool lets a builder put at most 6 processes on a card, so the 8-rank path of
+    bench.py — spawn_ranks, rendezvous on 127.0.0.1, shard.partition of ONE global batch of 8 x 1024 1080p images, barrier,
+    MAX-of-time / SUM-of-pixels agreement, rank 0's line — is rehearsed over gloo without a GPU (HJD_BENCH_DRY=1: nothing
+    is decoded and the line says so)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "0",
+                        "--batch", "1024", "--width", "1920", "--height", "1080"], env=_bench_env(HJD_BENCH_DRY="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["dry"] is True and line["n_gpus"] == 8
+    assert line["config"] == {"images_per_gpu": 1024, "global_images": 8192}
+    # SUM over the 8 ranks of their shards' pixels, MAX over the ranks of their (made-up) clocks: rank 7's 8 ms per step
+    assert abs(line["ms_per_step"] - 8.0) < 1e-6
+    assert abs(line["value"] - 8192 * 1920 * 1080 / 8.0e-3 / 1e6) < 1.0
+
+
+def test_a_dead_rank_ends_the_job_within_seconds():
+    """One of 8 ranks dies before the rendezvous (HJD_BENCH_FAIL_RANK): the other seven sit in init_process_group waiting for
+    it.  spawn_ranks polls every child, terminates the survivors and exits non-zero at once — not after the 10-30 min
+    process-group timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for bad in ("5", "0"):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                           env=_bench_env(HJD_BENCH_DRY="1", HJD_BENCH_FAIL_RANK=bad), capture_output=True, text=True, timeout=300)
+        dt = time.time() - t0
+        assert r.returncode != 0
+        assert "ranks failed" in r.stderr and "told to fail" in r.stderr
+        assert "n_gpus" not in r.stdout
+        assert dt < 60, dt  # eight interpreter + torch start-ups, then seconds

@@ -18,6 +18,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -72,7 +73,10 @@ def main():
             ent["wait_inst_frac"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
             ent["wait_any_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
         res[stage] = ent
-    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hjdtools as T
+    # stamped with the hash of the kernel sources the counters were collected on: bench.py ignores the file otherwise
+    json.dump({"kernel_src_sha16": T.kernel_src_hash(), "stages": res}, open(out, "w"), indent=1, sort_keys=True)
     for s, e in res.items():
         print(s, {a: b for a, b in e.items() if a not in ("counters",)})
 

@@ -13,11 +13,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
-STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair": "huff_repair", "k_write": "huff_write",
-            "k_unstuff_write": "unstuff", "k_dcapply": "dc_scan", "k_scan": "scan"}
+STAGE_OF = {"k_idct_color": "idct_color", "k_sync": "huff_sync", "k_repair_totals": "huff_repair", "k_write": "huff_write",
+            "k_unstuff_write": "unstuff", "k_unstuff_count": "unstuff_count", "k_dcapply": "dc_scan", "k_dcsum": "dc_sum", "k_scan": "scan"}
 
 
 def per_kernel(d, counter):
@@ -49,7 +50,10 @@ def main():
             "write_calibrated": k != "k_idct_color",
             "dispatches_averaged": [nf[k], nw[k]],
         }
-    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hjdtools as T
+    # stamped with the hash of the kernel sources the counters were collected on: bench.py ignores the file otherwise
+    json.dump({"kernel_src_sha16": T.kernel_src_hash(), "stages": res}, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 
 

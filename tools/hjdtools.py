@@ -11,6 +11,19 @@ _ENC = None
 _ORACLE = None
 
 
+def kernel_src_hash():
+    """sha256 (16 hex digits) over the kernel sources: profiles/ summaries carry it, bench.py ignores a summary whose stamp
+    differs from the sources it runs (the counters then describe another binary)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hls-jpeg-decoder_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _build(target_dir, so, cmd):
     path = os.path.join(ROOT, target_dir, so)
     if not os.path.exists(path):
