@@ -182,6 +182,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
     }
     uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
     uint32_t mnx = (m + 1u == nb) ? 0u : m + 1u;
+    uint2 nxt = L.mt[mnx]; // the NEXT block's table pair and successor, fetched a block ahead: no LDS round trip in the block-end step
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
@@ -258,9 +259,9 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
             nblk++;
             if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
             m = mnx;
-            const uint2 t = L.mt[m];
-            pair = t.x;
-            mnx = t.y;
+            pair = nxt.x;
+            mnx = nxt.y;
+            nxt = L.mt[mnx];
             tb = pair & 0xFFFFu;
         }
         const uint32_t tot = len + s;
@@ -281,6 +282,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 m = 0u;
                 pair = tabY;
                 mnx = L.mt[0].y;
+                nxt = L.mt[mnx];
                 tb = pair & 0xFFFFu;
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
@@ -300,6 +302,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 m = 0u;
                 pair = tabY;
                 mnx = L.mt[0].y;
+                nxt = L.mt[mnx];
                 tb = pair & 0xFFFFu;
                 rc.left = rc.ri_blocks;
                 rc.mk++;
@@ -327,16 +330,15 @@ struct RowEnv {
     uint32_t nmark;         // restart mode: markers found
 };
 
-template <bool WRITE>
+template <bool WRITE, class AfterPhase>
 __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
-                                           uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0)
+                                           uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0, AfterPhase after_phase)
 {
     const HjdParams &P = *E.P;
     const HjdImage &im = *E.im;
     const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, E.total_bits);
-    const uint32_t pair_lim = end > 32u ? end - 32u : 0u; // two-symbol steps of the synchronisation pass stop short of the row's end
     RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
     if (im.restart && active) {
         rc.nmark = E.nmark;
@@ -354,12 +356,53 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
         const uint32_t bit0 = sp + ph * WPP * 32u;
         const uint32_t pend = min(bit0 + WPP * 32u, end);
         const bool go = active && p < pend && (!WRITE || nblk < W.nblocks);
+        // Two-symbol steps of the synchronisation pass stop 32 bits short of the WINDOW's end: the state a decode holds at a
+        // window's end is then the first symbol boundary at or past it whatever pairs were taken before — the states passed
+        // on at a subsequence's end are those of the symbol-by-symbol final pass, and two decodes that have fallen into step
+        // show the same state at every window's end (the checkpoint comparison of sync_body relies on that).
+        const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u;
         if (go) {
             const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
             for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
             if (im.restart) decode_span<WRITE, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
             else decode_span<WRITE, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
         }
+        after_phase(ph);
+    }
+}
+
+// The same for ONE staging window (phase ph) of subsequence i — synchronisation only: the work items of a refinement
+// round advance a window at a time, so that those whose state has fallen into step with the subsequence's previous decode
+// can drop out (sync_body).
+__device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, uint32_t i, uint32_t ph, uint32_t &p, uint32_t &z, uint32_t &m,
+                                                  uint32_t &nblk, uint32_t &nrec)
+{
+    const HjdParams &P = *E.P;
+    const HjdImage &im = *E.im;
+    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
+    const uint32_t sp = i * S;
+    const uint32_t end = min(sp + S, E.total_bits);
+    const uint32_t bit0 = sp + ph * WPP * 32u;
+    const uint32_t pend = min(bit0 + WPP * 32u, end);
+    const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u; // as in decode_row
+    if (!(active && p < pend)) return;
+    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
+    uint32_t flags = 0;
+    WriteCtx W = {};
+    const uint32_t *src = row_base(E.wbase, i, lw) + (size_t)ph * WPP * 64u;
+    for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
+    if (im.restart) {
+        rc.nmark = E.nmark;
+        uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rc.mpos[mid] <= p) lo = mid + 1;
+            else hi = mid;
+        }
+        rc.mk = lo;
+        decode_span<false, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+    } else {
+        decode_span<false, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -372,11 +415,29 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
 // MODE 2: MODE 1 for the last repair launch, which also leaves the block / record totals of the final-pass
 //         workgroups it covers (k_scan's job when no repair launch is configured).
 
+// Synchronisation, MODE 0 (k_sync).
+// Round 0: every lane first decodes the last P.lane_warm staging windows of the subsequence BEFORE its own from a guess (a
+//   code boundary at the window's first bit, z = 0, MCU phase 0) — after ~1 kbit such a decode has fallen into step with the true one
+//   in 70 % of the cases — and takes the state it crosses its own first bit with as its start state.  From there it decodes
+//   its own subsequence and leaves, next to the end state, a CHECKPOINT at the end of each staging window (P.ckpt: decoder
+//   state there + blocks / records decoded inside that window).
+// Refinement rounds: a subsequence whose predecessor's end state differs from the start state it was decoded from becomes a
+//   WORK ITEM; the items are compacted onto the first lanes of the workgroup (__ballot + prefix over the waves) and every
+//   wave that holds items walks them window by window on its own (no barrier inside a round):
+//   * an item whose state at a window's end EQUALS the checkpoint of the subsequence's previous decode has fallen into step
+//     with it — same bit position, same zig-zag index, same block-in-MCU — so the rest of that decode stands: its end state is
+//     kept, its totals are corrected by the difference over the windows walked, and the item is done.  (Round 2 of this
+//     project re-decoded whole subsequences: 2.11 decodes per subsequence, every sparse round a full subsequence of latency.)
+//   * an item that reaches the end of its subsequence with a NEW end state walks on into the next subsequence unless that
+//     one is an item of this round itself: a state change runs down the chain inside one round instead of one
+//     subsequence per round.
+// MODE 1 / 2 (repair) use the same machinery without checkpoints (nothing to compare with: items walk whole subsequences).
 template <int MODE>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     constexpr uint32_t T = HJD_SYNC_WG;
+    static_assert(T <= 1024, "work items carry their slot in 10 bits");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
@@ -393,19 +454,24 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
     const uint32_t i = row0 + tid;
-    const bool valid = i < nsub && i < own1;
+    const uint32_t lim = min(own1, nsub); // subsequences [row0, lim) are this workgroup's slots
+    const bool valid = i < lim;
     const bool owned = valid && i >= own0;
     const uint32_t g = im.sub0 + i;
+    const uint32_t nph = (S >> 5) / P.phase_words;
 
-    // LDS: tables | per-slot state (end state, counts, work list) | staging windows
+    // LDS: tables | per-slot state | work list | staging windows
     uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
     uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word_s);
-    uint32_t *s_ep = s_dyn + P.lds_state_word_s;
-    uint32_t *s_ezm = s_ep + T;
-    uint32_t *s_cnt = s_ezm + T;
-    uint32_t *s_lp = s_cnt + T;   // work list: start bit position ...
-    uint32_t *s_lzm = s_lp + T;   // ... start z | m << 8 | slot << 16
-    uint32_t *s_wc = s_lzm + T;   // dirty subsequences per wave
+    uint32_t *s_ep = s_dyn + P.lds_state_word_s; // end state: bit position ...
+    uint32_t *s_up = s_ep + T;                   // the start state that end state was computed from: bit position ...
+    uint32_t *s_cnt = s_up + T;                  // blocks | records << 16 inside the subsequence
+    uint32_t *s_mark = s_cnt + T;                // last round in which the slot was a work item
+    uint32_t *s_lp = s_mark + T;                 // work list: start bit position,
+    uint32_t *s_lst = s_lp + T;                  //   z | m << 6 | slot << 9
+    uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_lst + T); // ... end state z | m << 8
+    uint16_t *s_uzm = s_ezm + T;                               // ... start state z | m << 8
+    uint32_t *s_wc = s_lst + 2 * T;              // work items per wave
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 16);
     uint32_t *s_rows = s_wc + 32;
     const HjdTableSet *ts = &P.tabs[im.tabset];
@@ -423,22 +489,60 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     E.total_bits = total_bits;
     E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
 
+    // checkpoints of this workgroup's slots: [window][slot], private to the workgroup (warm-up slots included)
+    uint2 *ck = MODE == 0 ? P.ckpt + (size_t)bid * nph * T : nullptr;
+
     const uint32_t sp = i * S;
-    uint32_t up = sp, uzm = 0;            // start state this slot's record was computed from (home lane's registers)
     uint32_t ext_p = sp, ext_zm = 0;      // start state offered to slot 0 from outside the workgroup
-    uint32_t flags = 0, ndec_total = 0;
+    // HJD_SYNC_PROF (diagnostics, tools/sync_profile.py): shader-clock stamps of this workgroup's stages
+    unsigned long long *dbg = (MODE == 0 && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
+    uint32_t dbg_k = 0;
+    auto stamp = [&](unsigned long long extra) {
+        if (dbg && tid == 0 && dbg_k < 30u) {
+            dbg[dbg_k++] = __builtin_readcyclecounter();
+            dbg[dbg_k++] = extra;
+        }
+    };
+    stamp(nsub);
+    uint32_t flags = 0, ndec_total = 0, nphase_items = 0;
     WriteCtx W = {};
+    s_mark[tid] = 0u;
+    (void)flags;
 
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
         __syncthreads();
-        // round 0: every subsequence from the guess (bit = its first bit, z = 0, MCU phase 0)
-        uint32_t p = sp, z = 0, m = 0, nblk = 0, nrec = 0;
-        decode_row<false>(E, valid, i, p, z, m, nblk, nrec, W, flags, 0u);
+        stamp(0);
+        // round 0: warm-up inside the lane, then the lane's own subsequence
+        uint32_t p = sp, z = 0, m = 0, nblk = 0, nrec = 0, cb = 0, cr = 0;
+        const uint32_t nw = min(P.lane_warm, nph);
+        if (nw != 0u) {
+            const bool wu = valid && i > 0u;
+            p = sp - nw * P.phase_words * 32u;
+            for (uint32_t ph = nph - nw; ph < nph; ph++) decode_phase_sync(E, wu, i - 1u, ph, p, z, m, nblk, nrec);
+            if (!wu || p < sp || p >= sp + 32u) { // no predecessor, or a marker jump took the walk elsewhere: the plain guess
+                p = sp;
+                z = 0;
+                m = 0;
+            }
+            nblk = 0;
+            nrec = 0;
+        }
+        stamp(1);
+        s_up[tid] = p;
+        s_uzm[tid] = (uint16_t)(z | (m << 8));
+        ext_p = p; // slot 0 has no predecessor inside the workgroup: its start state stands (the warm-up slots are there for that)
+        ext_zm = z | (m << 8);
+        decode_row<false>(E, valid, i, p, z, m, nblk, nrec, W, flags, 0u, [&](uint32_t ph) {
+            if (valid) ck[ph * T + tid] = make_uint2(p, z | (m << 6) | ((nblk - cb) << 9) | ((nrec - cr) << 20));
+            cb = nblk;
+            cr = nrec;
+        });
         s_ep[tid] = p;
-        s_ezm[tid] = z | (m << 8);
+        s_ezm[tid] = (uint16_t)(z | (m << 8));
         s_cnt[tid] = nblk | (nrec << 16);
-        ndec_total = min(own1, nsub) > row0 ? min(own1, nsub) - row0 : 0u;
+        ndec_total = lim > row0 ? lim - row0 : 0u;
+        nphase_items = valid ? nw : 0u;
     } else {
         uint4 r = make_uint4(sp, 0u, sp, 0u);
         uint32_t c = 0;
@@ -447,12 +551,12 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             c = P.subcnt[g];
         }
         s_ep[tid] = r.x;
-        s_ezm[tid] = r.y;
+        s_ezm[tid] = (uint16_t)r.y;
         s_cnt[tid] = c;
-        up = r.z;
-        uzm = r.w;
-        ext_p = up;
-        ext_zm = uzm;
+        s_up[tid] = r.z;
+        s_uzm[tid] = (uint16_t)r.w;
+        ext_p = r.z;
+        ext_zm = r.w;
         if (tid == 0 && valid && i > 0) {
             const uint4 pe = P.substate[g - 1];
             if (pe.x >= sp && pe.x < sp + 32u) { // a record's end always lies inside the next word
@@ -461,29 +565,31 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             }
         }
     }
+    stamp(2); // this wave's round 0 done
     __syncthreads();
+    stamp(3); // everybody's
 
     uint32_t rounds = 0;
     bool tables_loaded = MODE == 0;
     for (; rounds < 96u; rounds++) {
         // start state every slot should have: its predecessor's current end state
-        uint32_t wp = tid ? s_ep[tid - 1] : ext_p, wzm = tid ? s_ezm[tid - 1] : ext_zm;
+        uint32_t wp = tid ? s_ep[tid - 1] : ext_p, wzm = tid ? (uint32_t)s_ezm[tid - 1] : ext_zm;
         if (i == 0) {
             wp = 0;
             wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
         }
-        const bool dirty = valid && (wp != up || wzm != uzm);
-        const unsigned long long bal = __ballot(dirty);
+        const bool dirty = valid && (wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid]);
+        unsigned long long bal = __ballot(dirty);
         if (lane == 0) s_wc[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
-        uint32_t base = 0, ndirty = 0;
+        uint32_t base = 0, n = 0;
 #pragma unroll
         for (uint32_t q = 0; q < T / 64; q++) {
             const uint32_t c = s_wc[q];
             base += q < wv ? c : 0u;
-            ndirty += c;
+            n += c;
         }
-        if (ndirty == 0) break;
+        if (n == 0) break;
         if (MODE != 0 && !tables_loaded) {
             load_tables<true>(ts, s_lut, s_sec);
             tables_loaded = true;
@@ -491,24 +597,73 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         if (dirty) {
             const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             s_lp[t] = wp;
-            s_lzm[t] = wzm | (tid << 16);
-            up = wp;
-            uzm = wzm;
+            s_lst[t] = (wzm & 63u) | ((wzm >> 8) << 6) | (tid << 9);
+            s_up[tid] = wp;
+            s_uzm[tid] = (uint16_t)wzm;
+            s_mark[tid] = rounds + 1u;
         }
         __syncthreads();
-        if (wv * 64u < ndirty) { // waves without work go straight to the barrier
-            const bool work = tid < ndirty;
-            const uint32_t e = work ? s_lzm[tid] : 0u;
-            const uint32_t slot = e >> 16;
-            uint32_t p = work ? s_lp[tid] : 0u, z = e & 0xFFu, m = (e >> 8) & 0xFFu, nblk = 0, nrec = 0;
-            decode_row<false>(E, work, row0 + slot, p, z, m, nblk, nrec, W, flags, 0u);
-            if (work) {
-                s_ep[slot] = p;
-                s_ezm[slot] = z | (m << 8);
-                s_cnt[slot] = nblk | (nrec << 16);
+        stamp(0x100 + n);
+        // the round's items: every wave walks its own, window by window
+        uint32_t steps_done = 0;
+        if (wv * 64u < n) { // waves without work go straight to the barrier
+            bool live = tid < n;
+            const uint32_t st = live ? s_lst[tid] : 0u;
+            uint32_t slot = st >> 9, ph = 0u;
+            uint32_t p = live ? s_lp[tid] : 0u, z = st & 63u, m = (st >> 6) & 7u;
+            uint32_t cn = 0u, co = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
+            for (uint32_t step = 0; __any(live) && step < 65536u; step++) {
+                uint2 old = make_uint2(0xFFFFFFFFu, 0u);
+                if (MODE == 0 && live) old = ck[ph * T + slot]; // arrives while the window is decoded
+                uint32_t nblk = 0, nrec = 0;
+                decode_phase_sync(E, live, row0 + slot, ph, p, z, m, nblk, nrec);
+                steps_done++;
+                if (live) {
+                    nphase_items++;
+                    cn += nblk | (nrec << 16);
+                    const uint32_t st9 = z | (m << 6);
+                    const bool met = MODE == 0 && p == old.x && st9 == (old.y & 511u);
+                    if (MODE == 0) {
+                        co += ((old.y >> 9) & 2047u) | ((old.y >> 20) << 16);
+                        ck[ph * T + slot] = make_uint2(p, st9 | (nblk << 9) | (nrec << 20));
+                    }
+                    if (met) {
+                        // in step with the previous decode from here on: its end state stands, its totals change by the
+                        // difference over the windows walked (field-wise: no field of the sum can borrow)
+                        s_cnt[slot] = s_cnt[slot] + cn - co;
+                        live = false;
+                    } else if (ph + 1u < nph) {
+                        ph++;
+                    } else { // end of the subsequence with a state of its own
+                        s_ep[slot] = p;
+                        s_ezm[slot] = (uint16_t)(z | (m << 8));
+                        s_cnt[slot] = cn;
+                        const uint32_t nx = slot + 1u;
+                        live = nx < T && row0 + nx < lim && s_mark[nx] != rounds + 1u; // walk on: nobody else works on nx this round
+                        if (live) {
+                            s_mark[nx] = rounds + 1u;
+                            s_up[nx] = p;
+                            s_uzm[nx] = (uint16_t)(z | (m << 8));
+                            slot = nx;
+                            ph = 0u;
+                            cn = 0u;
+                            co = 0u;
+                        }
+                    }
+                }
             }
         }
-        ndec_total += ndirty;
+        stamp(0x10000 + steps_done); // wave 0's windows
+        __syncthreads();
+        stamp(0x20000);
+    }
+    {   // diagnostics: windows walked by all lanes -> subsequence decodes
+        __syncthreads();
+        if (tid == 0) s_wc[0] = 0u;
+        __syncthreads();
+        if (nphase_items) atomicAdd(&s_wc[0], nphase_items);
+        __syncthreads();
+        ndec_total += s_wc[0] / nph;
         __syncthreads();
     }
 
@@ -516,10 +671,10 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         const uint32_t c = valid ? s_cnt[tid] : 0u;
         const uint32_t tb = wave_incl_scan(c & 0xFFFFu);
         const uint32_t tr = wave_incl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u)); // every run is stored in whole bursts
-        __syncthreads(); // everyone is done with s_lp / s_lzm
+        __syncthreads(); // everyone is done with the work list
         if (lane == 63) {
             s_lp[wv] = tb;
-            s_lzm[wv] = tr;
+            s_lst[wv] = tr;
         }
         __syncthreads();
         if ((tid & (HJD_WRITE_WG - 1u)) == 0) {
@@ -527,7 +682,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             uint32_t sb = 0, sr = 0;
             for (uint32_t q = 0; q < HJD_WRITE_WG / 64; q++) {
                 sb += s_lp[w0 + q];
-                sr += s_lzm[w0 + q];
+                sr += s_lst[w0 + q];
             }
             if (wg * R + h < im.nwritewg) P.wgsum[im.writewg0 + wg * R + h] = make_uint2(sb, sr);
             if (wg == 0 && h == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
@@ -535,7 +690,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     }
     if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
     if (owned) {
-        P.substate[g] = make_uint4(s_ep[tid], s_ezm[tid], up, uzm);
+        P.substate[g] = make_uint4(s_ep[tid], (uint32_t)s_ezm[tid], s_up[tid], (uint32_t)s_uzm[tid]);
         P.subcnt[g] = s_cnt[tid];
     }
     if (tid == 0) { // diagnostics
@@ -659,7 +814,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
                   s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
     W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun elsewhere
     const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
-    decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0);
+    decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0, [](uint32_t) {});
     if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the subsequence ends inside a block
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);

@@ -17,6 +17,8 @@ struct HjdParams {
     uint8_t *mval;             // marker codes
     uint4 *substate;           // per subsequence: end state, start state used
     uint32_t *subcnt;          // per subsequence: blocks | records << 16
+    unsigned long long *dbg;   // diagnostics (HJD_SYNC_PROF=1): 32 words per synchronisation workgroup, else null
+    uint2 *ckpt;               // per synchronisation workgroup, [window][slot]: state at the window's end | blocks, records inside it
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
     uint4 *blk;                // per block: first record index, DC difference, slot mask lo, hi
@@ -36,6 +38,7 @@ struct HjdParams {
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
     uint32_t phase_words;      // words of a subsequence staged in LDS at a time (power of two, <= subseq_bits / 32)
+    uint32_t lane_warm;        // k_sync round 0: staging windows of the previous subsequence every lane decodes as warm-up
     uint32_t lds_sec_word;     // entropy kernels' dynamic LDS: word offset of the secondary tables
     uint32_t lds_state_word;   //                               word offset of the per-workgroup state arrays
     uint32_t lds_sec_word_s;   // the same two offsets for the synchronisation kernels (their primary tables are twice as large)

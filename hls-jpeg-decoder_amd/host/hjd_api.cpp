@@ -64,6 +64,18 @@ struct hjd_decoder {
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
     int streams = 0;           // image ranges a batch is split into (hjd_options.streams); 0 = by batch size
+    // Front-end concurrency limit (HJD_SYNC_CONC / hjd_options.reserved[0]): the synchronisation kernel is a latency chain that
+    // fills a fraction of the chip's issue slots; batches run on several caller streams otherwise march in lock step (all in
+    // their synchronisation at once, then all in their IDCT).  With a limit G the k-th run's synchronisation waits for that of
+    // run k-G: the runs spread out in time, so that at any moment some are in the latency-bound stage and the others in the
+    // issue-bound ones.  0 = no limit.
+    int sync_conc = 0;
+    std::mutex conc_mu;
+    hipEvent_t conc_ev[16] = {};
+    uint64_t conc_runs = 0;
+    int lane_warm = 0;         // k_sync round 0: warm-up windows per lane inside the previous subsequence; -1 = half a subsequence
+                               // (HJD_LANE_WARM: tuning knob; measured: same work and four windows more latency than none)
+    int stagger = 0;           // ranges of a batch run as a software pipeline (batch_enqueue): 0 off, 1 after sync, 2 after the final pass
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
     int conformant = 0;        // hjd_options.conformant: opt-in, outside the parity contract
     // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
@@ -100,6 +112,7 @@ struct hjd_batch {
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
+    std::vector<hipEvent_t> stagger_ev; // per range: recorded after its synchronisation (or final pass), the next range waits for it
     hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
     int dirty_decodes = 0;           // images decoded by the sequential emulation kernel since prepare
@@ -118,6 +131,8 @@ struct hjd_batch {
     uint32_t *d_chunk_kept = nullptr;
     uint4 *d_substate = nullptr;
     uint32_t *d_subcnt = nullptr;
+    uint2 *d_ckpt = nullptr;
+    unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
     uint4 *d_blk = nullptr;
     int16_t *d_dca = nullptr;
@@ -302,6 +317,9 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->dirty_mode = opt->dirty_mode ? 1 : 0;
         d->conformant = opt->conformant ? 1 : 0;
     }
+    if (const char *ew = getenv("HJD_LANE_WARM")) d->lane_warm = atoi(ew);
+    if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
+    if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) {
         d->subseq_bits = (uint32_t)atoi(e);
@@ -345,6 +363,8 @@ extern "C" void hjd_decoder_destroy(hjd_decoder *d)
             if (sl.down_done) (void)hipEventDestroy(sl.down_done);
             if (sl.h_out) (void)hipHostFree(sl.h_out);
         }
+        for (auto &e : d->conc_ev)
+            if (e) (void)hipEventDestroy(e);
         if (d->s_up) (void)hipStreamDestroy(d->s_up);
         if (d->s_run) (void)hipStreamDestroy(d->s_run);
         if (d->s_down) (void)hipStreamDestroy(d->s_down);
@@ -382,6 +402,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_chunk_kept);
     (void)hipFree(b->d_substate);
     (void)hipFree(b->d_subcnt);
+    (void)hipFree(b->d_ckpt);
+    (void)hipFree(b->d_dbg);
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_blk);
@@ -398,6 +420,8 @@ static void batch_free_device(hjd_batch *b)
     for (auto &st : b->istreams)
         if (st) (void)hipStreamDestroy(st);
     for (auto &e : b->join_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->stagger_ev)
         if (e) (void)hipEventDestroy(e);
     if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
 }
@@ -578,11 +602,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         uint32_t wpp = d->phase_words;
         if (wpp > S / 32) wpp = S / 32;
         P.phase_words = wpp;
+        {   // warm-up inside the lanes of k_sync's round 0: half a subsequence unless told otherwise
+            const uint32_t nph = (S / 32) / wpp;
+            P.lane_warm = d->lane_warm < 0 ? nph / 2 : ((uint32_t)d->lane_warm > nph ? nph : (uint32_t)d->lane_warm);
+        }
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_sync = (P.lds_state_word_s + 7 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
         P.lds_bytes_write = (P.lds_state_word + 64 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
@@ -601,6 +629,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_mval, b->nmarks + 1));
     need(slab_reserve(b, b->d_substate, sizeof(uint4) * b->nsub));
     need(slab_reserve(b, b->d_subcnt, sizeof(uint32_t) * b->nsub));
+    need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * (size_t)b->nsyncwg * HJD_SYNC_WG * ((S / 32) / P.phase_words)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint4) * (blk_cur + 1)));
@@ -690,6 +719,14 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.mval = b->d_mval;
     P.substate = b->d_substate;
     P.subcnt = b->d_subcnt;
+    P.ckpt = b->d_ckpt;
+    P.dbg = nullptr;
+    if (getenv("HJD_SYNC_PROF")) {
+        need(slab_reserve(b, b->d_dbg, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1)));
+        if (rcs != HJD_OK) return rcs;
+        HIPCHK(hipMemsetAsync(b->d_dbg, 0, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1), up));
+        P.dbg = b->d_dbg;
+    }
     P.wgsum = b->d_wgsum;
     P.rec = b->d_rec;
     P.blk = b->d_blk;
@@ -742,6 +779,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 }
                 b->istreams.push_back(st);
                 b->join_ev.push_back(e);
+                hipEvent_t se = nullptr;
+                HIPCHK(hipEventCreateWithFlags(&se, hipEventDisableTiming));
+                b->stagger_ev.push_back(se);
             }
             if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         }
@@ -836,6 +876,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->substate_entries = b.nsub;
     o->wgsum_entries = b.nwritewg;
     o->dcsum_entries = 3 * ((size_t)b.ndcchunks + 1);
+    o->ckpt_entries = (size_t)b.nsyncwg * HJD_SYNC_WG * ((b.P.subseq_bits / 32) / b.P.phase_words); // what batch_build allocates
     o->lds_bytes_sync = b.P.lds_bytes_sync;
     o->lds_bytes_write = b.P.lds_bytes_write;
     o->lds_state_word = b.P.lds_state_word;
@@ -884,7 +925,8 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
 // the kernel sequence; ev != nullptr records an event before each stage and one after the last
 // the kernel sequence for one range of images; names != nullptr records an event before each stage
 static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s, bool from_resync, int *nstage,
-                         const char **names, hipEvent_t *evs)
+                         const char **names, hipEvent_t *evs, hipEvent_t wait_before_sync = nullptr,
+                         hipEvent_t record_stagger = nullptr, int stagger_after = 0)
 {
     HjdParams P = b->P;
     P.off_chunk = r.chunk0;
@@ -910,8 +952,23 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     if (!from_resync) {
         if ((rc = mark("unstuff"))) return rc; // k_unstuff_count also clears the per-image state
         if (hjd_launch_unstuff(P, r.nchunk, s)) return HJD_ERR_INTERNAL;
+        // staggered ranges (batch_enqueue): this range's synchronisation — a latency chain that leaves most issue slots
+        // empty — starts when the previous range has finished its own, so that it runs beside that range's final pass and
+        // IDCT instead of beside three other synchronisation kernels
+        if (wait_before_sync && hipStreamWaitEvent(s, wait_before_sync, 0) != hipSuccess) return HJD_ERR_INTERNAL;
+        hipEvent_t conc_record = nullptr;
+        if (b->dec->sync_conc > 0 && !b->dry) { // front-end concurrency limit: see hjd_decoder::sync_conc
+            hjd_decoder *d = b->dec;
+            std::lock_guard<std::mutex> lk(d->conc_mu);
+            const uint64_t k = d->conc_runs++;
+            if (!d->conc_ev[k & 15] && hipEventCreateWithFlags(&d->conc_ev[k & 15], hipEventDisableTiming) != hipSuccess) return HJD_ERR_INTERNAL;
+            if (k >= (uint64_t)d->sync_conc && hipStreamWaitEvent(s, d->conc_ev[(k - d->sync_conc) & 15], 0) != hipSuccess) return HJD_ERR_INTERNAL;
+            conc_record = d->conc_ev[k & 15];
+        }
         if ((rc = mark("huff_sync"))) return rc;
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
+        if (record_stagger && stagger_after == 1 && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if ((rc = mark("huff_repair"))) return rc;
         for (int l = 0; l < nrep; l++)
             if (hjd_launch_sync(P, r.nrepwg, l + 1 == nrep ? 2 : 1, s)) return HJD_ERR_INTERNAL;
@@ -922,6 +979,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     }
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
+    if (record_stagger && stagger_after == 2 && !from_resync && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
     if (hjd_launch_dcscan(P, r.ndc, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
@@ -956,17 +1014,19 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         return range_enqueue(b, all, s, from_resync, nstage, names, evs);
     }
     // range 0 stays on the caller's stream, the others fork off it: n ranges occupy n hardware queues, not n + 1 (a
-    // process has four by default; a fifth stream shares one and serialises behind it)
+    // process has four by default; a fifth stream shares one and serialises behind it).  Ranges are enqueued in order,
+    // range k's synchronisation waiting for range k-1's (stagger = 1) or for range k-1's final pass (stagger = 2): the
+    // ranges then run as a software pipeline — one in its latency-bound synchronisation, the others in their
+    // issue-bound final pass / IDCT — instead of all in the same stage at the same time.
+    const int stagger = from_resync ? 0 : b->dec->stagger;
     HIPCHK(hipEventRecord(b->fork_ev, s));
-    for (size_t k = 1; k < b->ranges.size(); k++) {
-        HIPCHK(hipStreamWaitEvent(b->istreams[k], b->fork_ev, 0));
-        int rc = range_enqueue(b, b->ranges[k], b->istreams[k], from_resync, nullptr, nullptr, nullptr);
+    for (size_t k = 0; k < b->ranges.size(); k++) {
+        hipStream_t sk = k ? b->istreams[k] : s;
+        if (k) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0));
+        int rc = range_enqueue(b, b->ranges[k], sk, from_resync, nullptr, nullptr, nullptr,
+                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(b->join_ev[k], b->istreams[k]));
-    }
-    {
-        int rc = range_enqueue(b, b->ranges[0], s, from_resync, nullptr, nullptr, nullptr);
-        if (rc) return rc;
+        if (k) HIPCHK(hipEventRecord(b->join_ev[k], sk));
     }
     for (size_t k = 1; k < b->ranges.size(); k++) HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
     return HJD_OK;
@@ -1212,6 +1272,16 @@ extern "C" int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4)
     stats4[3] = (uint32_t)(((uint64_t)st.ustream_len * 8 + b->P.subseq_bits - 1) / b->P.subseq_bits);
     (void)im;
     return HJD_OK;
+}
+
+extern "C" int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, size_t cap_words)
+{
+    if (!b || !dst || !b->d_dbg) return -1;
+    DeviceGuard guard(b->device);
+    const size_t n = (size_t)b->nsyncwg * 32;
+    if (cap_words < n) return -1;
+    if (hipMemcpy(dst, b->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)b->nsyncwg;
 }
 
 extern "C" int hjd_batch_resync_count(const hjd_batch *b) { return b ? b->resyncs : -1; }

@@ -222,7 +222,7 @@ typedef struct hjd_layout_info {
     uint32_t nblocks, mcux, mcuy, nb, nchunks, nsub_cap, nsyncwg, nrepwg, nwritewg, ndcchunk, ngroups, groups_per_row;
     uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word, lds_state_word_sync;
     uint64_t raw_bytes, ustream_bytes, blk_entries, dca_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
-        dcsum_entries;
+        dcsum_entries, ckpt_entries;
 } hjd_layout_info;
 int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int sync_overlap, int out_format, hjd_layout_info *out);
 

@@ -82,9 +82,12 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         assert o.nwritewg <= o.wgsum_entries
         assert (T_ // WW) * (o.nrepwg - 1) < o.nwritewg + 1   # k_repair_totals writes wgsum[R*wg + h] only below nwritewg (guarded)
         # --- LDS of the entropy kernels: tables, state arrays, then one window of phase_words + 2 words per lane
-        assert o.lds_state_word_sync >= o.lds_state_word and o.lds_bytes_sync >= (o.lds_state_word_sync + 5 * T_ + 32 + (T_ // 64) * (o.phase_words + 2) * 64) * 4
+        assert o.lds_state_word_sync >= o.lds_state_word and o.lds_bytes_sync >= (o.lds_state_word_sync + 7 * T_ + 32 + (T_ // 64) * (o.phase_words + 2) * 64) * 4
         assert o.lds_bytes_write >= (o.lds_state_word + 64 + (WW // 64) * (o.phase_words + 2) * 64) * 4
         assert o.lds_bytes_sync <= 160 * 1024 and o.lds_bytes_write <= 160 * 1024
+        # --- checkpoints: k_sync workgroup w touches ckpt[(w * nph + ph) * T + slot], ph < nph = wps / phase_words, slot < T
+        nph = wps // o.phase_words
+        assert ((o.nsyncwg - 1) * nph + (nph - 1)) * T_ + (T_ - 1) < o.ckpt_entries
         # --- blocks: k_write stores blk[b] for b <= nblocks (closing entry); the IDCT kernel loads blk[b0 + tid], tid <= KB,
         #     and dca[b0 + tid], tid < KB, for the last group of the last MCU row: b0 + KB == nblocks
         assert o.nblocks == mcus * o.nb and o.nb == hf * vf + 2
