@@ -1,7 +1,6 @@
 // hjd_entropy.hip — Huffman VLC decode of the scan on gfx950 (MI355X, CDNA4).
 //   k_sync    ProcessHuffmanBlock, speculative: find the decoder state at every subsequence start
 //   k_repair  the same machinery re-run only where a workgroup's warm-up was too short
-//   k_scan    block / record totals per final-pass workgroup
 //   k_write   ProcessHuffmanBlock, final pass: coefficients out            (loadjpg.cpp:499-863)
 //
 // The scan of a baseline JPEG is one bit-serial string.  It is cut into fixed-size SUBSEQUENCES
@@ -330,16 +329,18 @@ struct RowEnv {
     uint32_t nmark;         // restart mode: markers found
 };
 
-template <bool WRITE, class AfterPhase>
-__device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
-                                           uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0, AfterPhase after_phase)
+template <class AfterPhase>
+__device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
+                                                uint32_t &nblk, uint32_t &nrec, AfterPhase after_phase)
 {
     const HjdParams &P = *E.P;
     const HjdImage &im = *E.im;
     const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, E.total_bits);
-    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
+    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
+    uint32_t flags = 0;
+    WriteCtx W = {};
     if (im.restart && active) {
         rc.nmark = E.nmark;
         uint32_t lo = 0, hi = rc.nmark; // first marker past the start of this row
@@ -355,19 +356,50 @@ __device__ __forceinline__ void decode_row(const RowEnv &E, bool active, uint32_
     for (uint32_t ph = 0; ph < nph; ph++) {
         const uint32_t bit0 = sp + ph * WPP * 32u;
         const uint32_t pend = min(bit0 + WPP * 32u, end);
-        const bool go = active && p < pend && (!WRITE || nblk < W.nblocks);
+        const bool go = active && p < pend;
         // Two-symbol steps of the synchronisation pass stop 32 bits short of the WINDOW's end: the state a decode holds at a
         // window's end is then the first symbol boundary at or past it whatever pairs were taken before — the states passed
-        // on at a subsequence's end are those of the symbol-by-symbol final pass, and two decodes that have fallen into step
+        // on at a window's end are those of the symbol-by-symbol final pass, and two decodes that have fallen into step
         // show the same state at every window's end (the checkpoint comparison of sync_body relies on that).
         const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u;
         if (go) {
             const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
             for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-            if (im.restart) decode_span<WRITE, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
-            else decode_span<WRITE, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+            if (im.restart) decode_span<false, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+            else decode_span<false, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
         }
         after_phase(ph);
+    }
+}
+
+// Final pass over ONE staging window (phase ph) of subsequence i (k_write).  left0 = blocks left in the restart interval
+// the lane's first block lies in.
+__device__ __forceinline__ void decode_window_write(const RowEnv &E, bool active, uint32_t i, uint32_t ph, uint32_t &p, uint32_t &z, uint32_t &m,
+                                                    uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0)
+{
+    const HjdParams &P = *E.P;
+    const HjdImage &im = *E.im;
+    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
+    const uint32_t sp = i * S;
+    const uint32_t end = min(sp + S, E.total_bits);
+    const uint32_t bit0 = sp + ph * WPP * 32u;
+    const uint32_t pend = min(bit0 + WPP * 32u, end);
+    if (!(active && p < pend && nblk < W.nblocks)) return;
+    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
+    const uint32_t *src = row_base(E.wbase, i, lw) + (size_t)ph * WPP * 64u;
+    for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
+    if (im.restart) {
+        rc.nmark = E.nmark;
+        uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rc.mpos[mid] <= p) lo = mid + 1;
+            else hi = mid;
+        }
+        rc.mk = lo;
+        decode_span<true, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, 0u, nblk, nrec, W, flags, rc);
+    } else {
+        decode_span<true, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, 0u, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -431,7 +463,7 @@ __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, 
 //   * an item that reaches the end of its subsequence with a NEW end state walks on into the next subsequence unless that
 //     one is an item of this round itself: a state change runs down the chain inside one round instead of one
 //     subsequence per round.
-// MODE 1 / 2 (repair) use the same machinery without checkpoints (nothing to compare with: items walk whole subsequences).
+// MODE 1 / 2 (repair) use the same machinery on the records and checkpoints k_sync left (no round 0, no warm-up slots).
 template <int MODE>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
@@ -443,7 +475,6 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
     const int ii = (int)(MODE == 0 ? P.map_syncwg[bid] : P.map_repwg[bid]);
     static_assert(HJD_SYNC_WG % HJD_WRITE_WG == 0, "a repair workgroup covers whole final-pass workgroups");
-    constexpr uint32_t R = HJD_SYNC_WG / HJD_WRITE_WG;
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
     const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
@@ -489,8 +520,15 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     E.total_bits = total_bits;
     E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
 
-    // checkpoints of this workgroup's slots: [window][slot], private to the workgroup (warm-up slots included)
-    uint2 *ck = MODE == 0 ? P.ckpt + (size_t)bid * nph * T : nullptr;
+    // Checkpoints (HjdParams::ckpt): a subsequence the workgroup OWNS has its entries at their canonical place — the
+    // image's [window][subsequence] array, which k_write and the repair kernels read — its warm-up slots' entries live in a
+    // scratch area private to the workgroup.
+    uint2 *const ck_canon = P.ckpt + (size_t)im.sub0 * nph + row0;       // + window * nsub_cap + slot
+    uint2 *const ck_scr = P.ckpt + P.ck_scratch + (size_t)bid * nph * K; // + window * K + slot        (MODE 0, slot < nwarm)
+    const uint32_t nwarm = own0 - row0;
+    auto ck = [&](uint32_t ph, uint32_t slot) -> uint2 * {
+        return slot >= nwarm ? ck_canon + (size_t)ph * im.nsub_cap + slot : ck_scr + ph * K + slot;
+    };
 
     const uint32_t sp = i * S;
     uint32_t ext_p = sp, ext_zm = 0;      // start state offered to slot 0 from outside the workgroup
@@ -504,10 +542,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         }
     };
     stamp(nsub);
-    uint32_t flags = 0, ndec_total = 0, nphase_items = 0;
-    WriteCtx W = {};
+    uint32_t ndec_total = 0, nphase_items = 0;
     s_mark[tid] = 0u;
-    (void)flags;
 
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
@@ -533,8 +569,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         s_uzm[tid] = (uint16_t)(z | (m << 8));
         ext_p = p; // slot 0 has no predecessor inside the workgroup: its start state stands (the warm-up slots are there for that)
         ext_zm = z | (m << 8);
-        decode_row<false>(E, valid, i, p, z, m, nblk, nrec, W, flags, 0u, [&](uint32_t ph) {
-            if (valid) ck[ph * T + tid] = make_uint2(p, z | (m << 6) | ((nblk - cb) << 9) | ((nrec - cr) << 20));
+        decode_row_sync(E, valid, i, p, z, m, nblk, nrec, [&](uint32_t ph) {
+            if (valid) *ck(ph, tid) = make_uint2(p, z | (m << 6) | ((nblk - cb) << 9) | ((nrec - cr) << 20));
             cb = nblk;
             cr = nrec;
         });
@@ -614,7 +650,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             uint32_t cn = 0u, co = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
             for (uint32_t step = 0; __any(live) && step < 65536u; step++) {
                 uint2 old = make_uint2(0xFFFFFFFFu, 0u);
-                if (MODE == 0 && live) old = ck[ph * T + slot]; // arrives while the window is decoded
+                if (live) old = *ck(ph, slot); // arrives while the window is decoded
                 uint32_t nblk = 0, nrec = 0;
                 decode_phase_sync(E, live, row0 + slot, ph, p, z, m, nblk, nrec);
                 steps_done++;
@@ -622,11 +658,9 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     nphase_items++;
                     cn += nblk | (nrec << 16);
                     const uint32_t st9 = z | (m << 6);
-                    const bool met = MODE == 0 && p == old.x && st9 == (old.y & 511u);
-                    if (MODE == 0) {
-                        co += ((old.y >> 9) & 2047u) | ((old.y >> 20) << 16);
-                        ck[ph * T + slot] = make_uint2(p, st9 | (nblk << 9) | (nrec << 20));
-                    }
+                    const bool met = p == old.x && st9 == (old.y & 511u);
+                    co += ((old.y >> 9) & 2047u) | ((old.y >> 20) << 16);
+                    *ck(ph, slot) = make_uint2(p, st9 | (nblk << 9) | (nrec << 20));
                     if (met) {
                         // in step with the previous decode from here on: its end state stands, its totals change by the
                         // difference over the windows walked (field-wise: no field of the sum can borrow)
@@ -667,25 +701,67 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         __syncthreads();
     }
 
-    if (MODE == 2) { // totals of the two final-pass workgroups whose subsequences this workgroup holds
-        const uint32_t c = valid ? s_cnt[tid] : 0u;
-        const uint32_t tb = wave_incl_scan(c & 0xFFFFu);
-        const uint32_t tr = wave_incl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u)); // every run is stored in whole bursts
+    if (MODE == 0) {
+        // Totals of the final-pass workgroups: k_write runs one lane per staging WINDOW and places its outputs by prefix
+        // sums over the windows' block / record counts; the sums over everything BEFORE a final-pass workgroup come from
+        // per-workgroup totals (P.wgsum, zeroed by k_unstuff_count).  A final-pass workgroup covers G = HJD_WRITE_WG / nph
+        // subsequences, which a synchronisation workgroup's range [own0, own1) cuts anywhere: LDS atomics per group, then one
+        // global atomic per group and counter.  (Round 2 left this to a launch of its own — a 512-lane, 60 KB-LDS gate that
+        // sat 0.2 ms waiting for a CU beside the other streams' kernels.  A stale workgroup border is still caught: k_write
+        // checks the induction step for every subsequence and the host re-synchronises.)
+        const uint32_t G = HJD_WRITE_WG / nph; // nph is a power of two <= 64
+        const uint32_t wq0 = own0 / G;
         __syncthreads(); // everyone is done with the work list
-        if (lane == 63) {
-            s_lp[wv] = tb;
-            s_lst[wv] = tr;
+        s_lp[tid] = 0u;
+        s_lst[tid] = 0u;
+        __syncthreads();
+        if (owned) {
+            uint32_t sb = 0, sr = 0;
+            for (uint32_t ph = 0; ph < nph; ph++) {
+                const uint32_t c = ck(ph, tid)->y;
+                sb += (c >> 9) & 2047u;
+                sr += ((c >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
+            }
+            atomicAdd(&s_lp[i / G - wq0], sb);
+            atomicAdd(&s_lst[i / G - wq0], sr);
         }
         __syncthreads();
-        if ((tid & (HJD_WRITE_WG - 1u)) == 0) {
-            const uint32_t h = tid / HJD_WRITE_WG, w0 = h * (HJD_WRITE_WG / 64);
-            uint32_t sb = 0, sr = 0;
-            for (uint32_t q = 0; q < HJD_WRITE_WG / 64; q++) {
-                sb += s_lp[w0 + q];
-                sr += s_lst[w0 + q];
+        const uint32_t wq = wq0 + tid;
+        if (tid <= (own1 - 1u) / G - wq0 && wq < im.nwritewg && (s_lp[tid] | s_lst[tid])) {
+            atomicAdd(&P.wgsum[im.writewg0 + wq].x, s_lp[tid]);
+            atomicAdd(&P.wgsum[im.writewg0 + wq].y, s_lst[tid]);
+        }
+        if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
+    }
+    if (MODE == 2) {
+        // The same totals after a repair (host re-synchronisation): written, not added — a repair workgroup holds whole groups.
+        const uint32_t G = HJD_WRITE_WG / nph;
+        uint32_t sb = 0, sr = 0;
+        if (valid)
+            for (uint32_t ph = 0; ph < nph; ph++) {
+                const uint32_t c = ck(ph, tid)->y;
+                sb += (c >> 9) & 2047u;
+                sr += ((c >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
             }
-            if (wg * R + h < im.nwritewg) P.wgsum[im.writewg0 + wg * R + h] = make_uint2(sb, sr);
-            if (wg == 0 && h == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
+        const uint32_t ib = wave_incl_scan(sb), ir = wave_incl_scan(sr);
+        __syncthreads(); // everyone is done with the work list
+        s_lp[tid] = ib;
+        s_lst[tid] = ir;
+        __syncthreads();
+        if ((tid & (G - 1u)) == 0) {
+            uint32_t tb = 0, tr = 0;
+            if (G >= 64u) {
+                for (uint32_t q = 0; q < G / 64u; q++) {
+                    tb += s_lp[tid + 64u * q + 63u];
+                    tr += s_lst[tid + 64u * q + 63u];
+                }
+            } else {
+                tb = s_lp[tid + G - 1u] - (lane ? s_lp[tid - 1u] : 0u);
+                tr = s_lst[tid + G - 1u] - (lane ? s_lst[tid - 1u] : 0u);
+            }
+            const uint32_t wq = wg * (T / G) + tid / G;
+            if (wq < im.nwritewg) P.wgsum[im.writewg0 + wq] = make_uint2(tb, tr);
+            if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
         }
     }
     if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
@@ -706,31 +782,11 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P) { sync_body<0
 __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair(HjdParams P) { sync_body<1>(P); }
 __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair_totals(HjdParams P) { sync_body<2>(P); }
 
-// ---- stage 2: totals per final-pass workgroup ---------------------------------------------------
-// k_write places its outputs by exclusive prefix sums over the subsequences' block and record counts;
-// the sums over everything BEFORE a workgroup come from these per-workgroup totals.
-
-__global__ __launch_bounds__(HJD_WRITE_WG) void k_scan(HjdParams P)
-{
-    __shared__ uint32_t s_w[17];
-    const uint32_t bid = blockIdx.x + P.off_writewg;
-    const int ii = (int)P.map_writewg[bid];
-    const HjdImage &im = P.img[ii];
-    const uint32_t S = P.subseq_bits;
-    const uint32_t nsub = (P.st[ii].ustream_len * 8u + S - 1) / S;
-    const uint32_t i = (bid - im.writewg0) * HJD_WRITE_WG + threadIdx.x;
-    const uint32_t c = i < nsub ? P.subcnt[im.sub0 + i] : 0u;
-    uint32_t tb, tr;
-    block_excl_scan(c & 0xFFFFu, s_w, &tb);
-    block_excl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tr); // every run is stored in whole bursts
-    if (threadIdx.x == 0) {
-        P.wgsum[bid] = make_uint2(tb, tr);
-        if (bid == im.writewg0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
-    }
-}
-
 // ---- stage 3: final entropy decode, coefficients out ------------------------------------------
 
+// One lane per staging WINDOW of a subsequence (256 bits by default): k_sync's checkpoints hold the decoder state at every
+// window's end and the blocks / records decoded inside every window, so the final pass can start anywhere a window starts.
+// (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.)
 __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -749,20 +805,22 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t *s_rows = s_w + 64;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
-    const uint32_t S = P.subseq_bits;
+    const uint32_t S = P.subseq_bits, nph = (S >> 5) / P.phase_words;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    if (wg * HJD_WRITE_WG >= nsub) return; // capacity-based grid: nothing in this workgroup
+    if (wg * HJD_WRITE_WG >= nsub * nph) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
 
-    const uint32_t i = wg * HJD_WRITE_WG + tid;
+    const uint32_t u = wg * HJD_WRITE_WG + tid; // window number
+    const uint32_t i = u / nph, ph = u % nph;
     const bool valid = i < nsub;
     const uint32_t g = im.sub0 + i;
+    const uint2 *ckc = P.ckpt + (size_t)im.sub0 * nph; // [window][subsequence] of this image
+    const uint2 mine = valid ? ckc[(size_t)ph * im.nsub_cap + i] : make_uint2(0u, 0u);
 
-    // where this subsequence's blocks and records go: totals of the workgroups before this one + scan inside
-    const uint32_t c = valid ? P.subcnt[g] : 0u;
+    // where this window's blocks and records go: totals of the workgroups before this one + scan inside
     uint32_t pb = 0, pr = 0;
     for (uint32_t k = tid; k < wg; k += HJD_WRITE_WG) {
         const uint2 t = P.wgsum[im.writewg0 + k];
@@ -772,10 +830,10 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t base_b, base_r, tot_b, tot_r;
     block_excl_scan(pb, s_w, &base_b);
     block_excl_scan(pr, s_w, &base_r);
-    uint32_t blk = base_b + block_excl_scan(c & 0xFFFFu, s_w, &tot_b);
-    uint32_t nrec = base_r + block_excl_scan(((c >> 16) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
+    uint32_t blk = base_b + block_excl_scan((mine.y >> 9) & 2047u, s_w, &tot_b);
+    uint32_t nrec = base_r + block_excl_scan(((mine.y >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
     uint32_t flags = 0;
-    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub) { // the workgroup that holds the last subsequence
+    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub * nph) { // the workgroup that holds the last window
         P.st[ii].total_blocks = base_b + tot_b;
         if (base_b + tot_b < im.nblocks) flags |= HJD_FLAG_SHORT;
     }
@@ -792,30 +850,46 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     E.total_bits = total_bits;
     E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
 
-    // induction step: this subsequence's record must have been computed from its predecessor's end state
-    uint32_t p = 0, zm = 0;
+    // start state: the checkpoint at the end of the window before; at a subsequence's first window the induction step
+    // is checked — the subsequence's record must have been computed from its predecessor's end state
+    uint32_t p = 0, z = 0, m = 0;
     bool go = valid;
     if (valid) {
-        if (i > 0) {
-            const uint4 pe = P.substate[g - 1];
-            p = pe.x;
-            zm = pe.y;
-        }
-        const uint4 me = P.substate[g];
-        if (me.z != p || me.w != zm || p < i * S || p >= i * S + 32u) {
-            flags |= HJD_FLAG_NOT_CONVERGED; // host re-synchronises
-            go = false;
+        if (ph != 0u) {
+            const uint2 st = ckc[(size_t)(ph - 1u) * im.nsub_cap + i];
+            p = st.x;
+            z = st.y & 63u;
+            m = (st.y >> 6) & 7u;
+        } else {
+            uint32_t zm = 0;
+            if (i > 0) {
+                const uint4 pe = P.substate[g - 1];
+                p = pe.x;
+                zm = pe.y;
+            }
+            const uint4 me = P.substate[g];
+            if (me.z != p || me.w != zm || p < i * S || p >= i * S + 32u) {
+                flags |= HJD_FLAG_NOT_CONVERGED; // host re-synchronises
+                go = false;
+            }
+            z = zm & 0xFFu;
+            m = zm >> 8;
         }
     }
     __syncthreads(); // tables are in LDS
 
-    uint32_t z = zm & 0xFFu, m = zm >> 8;
     WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks,
                   s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
     W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun elsewhere
     const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
-    decode_row<true>(E, go, i, p, z, m, blk, nrec, W, flags, left0, [](uint32_t) {});
-    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the subsequence ends inside a block
+    const uint32_t nrec0 = nrec;
+    decode_window_write(E, go, i, ph, p, z, m, blk, nrec, W, flags, left0);
+    // the window must end in the state, and with the record count, its checkpoint holds (else the places of everything
+    // after it are wrong: the host re-synchronises) — unless the image was complete before the window's end
+    if (go && blk < im.nblocks && !(flags & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN)) &&
+        (p != mine.x || (z | (m << 6)) != (mine.y & 511u) || nrec - nrec0 != (mine.y >> 20)))
+        flags |= HJD_FLAG_NOT_CONVERGED;
+    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the window ends inside a block
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
         for (uint32_t q = k; q < HJD_REC_RUN; q++) {
@@ -863,14 +937,6 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
         if (set_dyn_lds(2, reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
     }
-    hipError_t e_ = hipGetLastError();
-    return e_ == hipSuccess ? 0 : (int)e_;
-}
-
-int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s)
-{
-    if (!nwritewg) return 0;
-    hipLaunchKernelGGL(k_scan, dim3(nwritewg), dim3(HJD_WRITE_WG), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -18,7 +18,10 @@ struct HjdParams {
     uint4 *substate;           // per subsequence: end state, start state used
     uint32_t *subcnt;          // per subsequence: blocks | records << 16
     unsigned long long *dbg;   // diagnostics (HJD_SYNC_PROF=1): 32 words per synchronisation workgroup, else null
-    uint2 *ckpt;               // per synchronisation workgroup, [window][slot]: state at the window's end | blocks, records inside it
+    uint2 *ckpt;               // checkpoints, per image [window][subsequence]: x = bit position at the window's end, y = z | m << 6 |
+                               // blocks inside the window << 9 | records inside it << 20; after ck_scratch entries: k_sync's
+                               // private copies for its warm-up slots, per workgroup [window][slot < sync_overlap]
+    uint64_t ck_scratch;       // first entry of that scratch area
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
     uint4 *blk;                // per block: first record index, DC difference, slot mask lo, hi
@@ -49,7 +52,6 @@ struct HjdParams {
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s);
-int hjd_launch_scan(const HjdParams &P, uint32_t nwritewg, hipStream_t s);
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

@@ -215,8 +215,13 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
 
 // CONF: conformant mode (hjd_options.conformant) — a separate instantiation, so that the default kernel carries none of
 // its branches (as run-time branches they cost 4 % of the kernel); every image of a batch has the decoder's setting.
+#ifdef HJD_IDCT_WAVES // experiment: cap the resident waves per SIMD so that other streams' large-LDS workgroups find room beside this kernel
+#define HJD_IDCT_OCC __attribute__((amdgpu_waves_per_eu(HJD_IDCT_WAVES, HJD_IDCT_WAVES)))
+#else
+#define HJD_IDCT_OCC
+#endif
 template <bool CONF>
-__global__ __launch_bounds__(256) void k_idct_color(HjdParams P)
+__global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
 {
     __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index = slot u*8+v (u = horizontal frequency); +2 pad: bank spread
     __shared__ uint32_t s_mask[MAXGB][2]; // bit = slot holds a coefficient (lo: slots 0-31, hi: 32-63)

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(HjdParams P)
             P.st[ii] = z;
         }
     }
+    if (c == im.chunk0) // ... and the final-pass workgroups' totals, which k_sync adds up
+        for (uint32_t k = threadIdx.x; k < im.nwritewg; k += UNSTUFF_T) P.wgsum[im.writewg0 + k] = make_uint2(0u, 0u);
 }
 
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)

@@ -58,18 +58,18 @@ struct hjd_decoder {
     uint32_t subseq_bits = 2048;
     bool subseq_auto = true;    // no explicit size: chosen per batch from the amount of scan data (batch_build)
     bool overlap_auto = true;
-    int sync_launches = 2; // one synchronisation launch + one repair launch (a gate that returns at once unless a
-                           // workgroup's 16 kbit of warm-up were not enough; whatever it leaves is caught by
-                           // k_write's induction check and repaired from the host)
+    int sync_launches = 1; // the synchronisation launch, plus this many - 1 in-stream repair launches (gates that return at once
+                           // unless a workgroup's 16 kbit of warm-up were not enough).  Default none: k_write checks the
+                           // induction step for every subsequence and hjd_batch_finish repairs from the host
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
-    uint32_t phase_words = 8;  // words of a subsequence staged in LDS at a time
+    uint32_t phase_words = 16; // words of a subsequence staged in LDS at a time = the window one k_write lane decodes
     int streams = 0;           // image ranges a batch is split into (hjd_options.streams); 0 = by batch size
     // Front-end concurrency limit (HJD_SYNC_CONC / hjd_options.reserved[0]): the synchronisation kernel is a latency chain that
     // fills a fraction of the chip's issue slots; batches run on several caller streams otherwise march in lock step (all in
     // their synchronisation at once, then all in their IDCT).  With a limit G the k-th run's synchronisation waits for that of
     // run k-G: the runs spread out in time, so that at any moment some are in the latency-bound stage and the others in the
     // issue-bound ones.  0 = no limit.
-    int sync_conc = 0;
+    int sync_conc = 2;
     std::mutex conc_mu;
     hipEvent_t conc_ev[16] = {};
     uint64_t conc_runs = 0;
@@ -304,7 +304,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     d->device = device;
     if (opt) {
         if (opt->subseq_bits) {
-            if (opt->subseq_bits < 64 || opt->subseq_bits > 4096 || (opt->subseq_bits & (opt->subseq_bits - 1))) {
+            if (opt->subseq_bits < 64 || opt->subseq_bits > 16384 || (opt->subseq_bits & (opt->subseq_bits - 1))) {
                 delete d;
                 hjd_set_last_status(HJD_ERR_ARG);
                 return nullptr;
@@ -321,7 +321,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
-    if (e && atoi(e) >= 64 && atoi(e) <= 4096 && (atoi(e) & (atoi(e) - 1)) == 0) {
+    if (e && atoi(e) >= 64 && atoi(e) <= 16384 && (atoi(e) & (atoi(e) - 1)) == 0) {
         d->subseq_bits = (uint32_t)atoi(e);
         d->subseq_auto = false;
     }
@@ -450,22 +450,25 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->dirty_decodes = 0;
     DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
-    // Subsequence size: every lane of the entropy kernels decodes one subsequence serially, so a small batch wants short
-    // ones (one 4K image: 0.43 ms at 256 bits against 0.65 ms at 2048) and a large batch long ones (fewer wasted
-    // synchronisation decodes: 16 x 4K, 2048 bits).  Unless the caller fixed it: the largest power of two that still
-    // leaves about 65536 subsequences (256 CUs x 256 lanes of the final pass), within 256..2048.
+    // Subsequence size: every lane of k_sync decodes one subsequence serially (k_write runs one lane per staging window whatever
+    // the subsequence size), so a small batch wants short ones and a large batch long ones (fewer synchronisation
+    // workgroups, tables loaded less often: 64 x 4K on four streams, 240 Gpixel/s at 2048 bits, 270 at 4096).  Unless the
+    // caller fixed it: the largest power of two that still leaves about 32768 subsequences, within 256..4096.
     uint32_t S = d->subseq_bits, K = d->sync_overlap;
     if (d->subseq_auto) {
         uint64_t bits = 0;
         for (int i = 0; i < b->n; i++)
             if (b->parse_status[i] == HJD_OK) bits += (uint64_t)parsed[i].stream_len * 8u;
         S = 256;
-        while (S < 2048 && (uint64_t)S * 2u * 65536u <= bits) S *= 2;
+        while (S < 4096 && (uint64_t)S * 2u * 32768u <= bits) S *= 2;
         if (d->overlap_auto) {
             const uint32_t k = 16384 / S;
             K = k < 4 ? 4 : (k > 32 ? 32 : k);
         }
     }
+    uint32_t wpp = d->phase_words; // staging window of the entropy kernels, in words; k_write runs one lane per window
+    if (wpp > S / 32) wpp = S / 32;
+    const uint32_t nph = (S / 32) / wpp; // windows per subsequence
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, blk_cur = 0, rec_cur = 0, out_cur = 0;
@@ -522,7 +525,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.nrepwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
         b->nrepwg += im.nrepwg;
         im.writewg0 = b->nwritewg;
-        im.nwritewg = (im.nsub_cap + HJD_WRITE_WG - 1) / HJD_WRITE_WG;
+        im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nph + HJD_WRITE_WG - 1) / HJD_WRITE_WG); // one lane per window
         b->nwritewg += im.nwritewg;
         im.dcchunk0 = b->ndcchunks;
         im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
@@ -564,7 +567,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             // With DRI the reference may leave the marker grid and finish its blocks on the zeros past the end of the
             // scan (sequential emulation, hjd_seq.hip): only the per-block bound holds there.
             const uint64_t bound = im.restart ? by_blocks : (by_blocks < by_bits ? by_blocks : by_bits);
-            const uint64_t cap = bound + (uint64_t)HJD_REC_RUN * im.nsub_cap + 64;
+            const uint64_t cap = bound + (uint64_t)HJD_REC_RUN * im.nsub_cap * nph + 64; // every window's run ends in a whole burst
             im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~(uint32_t)(HJD_REC_RUN - 1);
         }
         im.rec_off = rec_cur;
@@ -599,8 +602,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.sync_overlap = K;
     {   // dynamic LDS of the entropy kernels: primary and secondary tables, per-workgroup state, then one
         // staging window of phase_words + 2 words per lane
-        uint32_t wpp = d->phase_words;
-        if (wpp > S / 32) wpp = S / 32;
         P.phase_words = wpp;
         {   // warm-up inside the lanes of k_sync's round 0: half a subsequence unless told otherwise
             const uint32_t nph = (S / 32) / wpp;
@@ -629,7 +630,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_mval, b->nmarks + 1));
     need(slab_reserve(b, b->d_substate, sizeof(uint4) * b->nsub));
     need(slab_reserve(b, b->d_subcnt, sizeof(uint32_t) * b->nsub));
-    need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * (size_t)b->nsyncwg * HJD_SYNC_WG * ((S / 32) / P.phase_words)));
+    P.ck_scratch = (uint64_t)b->nsub * nph; // canonical entries first, then k_sync's private ones for its warm-up slots
+    need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * ((size_t)b->nsub * nph + (size_t)b->nsyncwg * nph * K + 1)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint4) * (blk_cur + 1)));
@@ -876,7 +878,10 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->substate_entries = b.nsub;
     o->wgsum_entries = b.nwritewg;
     o->dcsum_entries = 3 * ((size_t)b.ndcchunks + 1);
-    o->ckpt_entries = (size_t)b.nsyncwg * HJD_SYNC_WG * ((b.P.subseq_bits / 32) / b.P.phase_words); // what batch_build allocates
+    {   // what batch_build allocates
+        const size_t nph = (b.P.subseq_bits / 32) / b.P.phase_words;
+        o->ckpt_entries = (size_t)b.nsub * nph + (size_t)b.nsyncwg * nph * b.P.sync_overlap + 1;
+    }
     o->lds_bytes_sync = b.P.lds_bytes_sync;
     o->lds_bytes_write = b.P.lds_bytes_write;
     o->lds_state_word = b.P.lds_state_word;
@@ -969,10 +974,9 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
         if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (record_stagger && stagger_after == 1 && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
-        if ((rc = mark("huff_repair"))) return rc;
+        if (nrep > 0 && (rc = mark("huff_repair"))) return rc;
         for (int l = 0; l < nrep; l++)
             if (hjd_launch_sync(P, r.nrepwg, l + 1 == nrep ? 2 : 1, s)) return HJD_ERR_INTERNAL;
-        if (nrep <= 0 && hjd_launch_scan(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     } else {
         if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
         if (hjd_launch_sync(P, r.nrepwg, 2, s)) return HJD_ERR_INTERNAL;

@@ -112,7 +112,7 @@ typedef enum hjd_out_format {
 } hjd_out_format;
 
 typedef struct hjd_options {
-    int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..4096); 0 = chosen per batch from its scan bytes (256..2048) */
+    int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..16384); 0 = chosen per batch from its scan bytes */
     int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
     int streams;         /* image ranges a batch is split into, each on its own HIP stream (the first on the caller's; the
                           * others forked from and joined to it): one range's latency-bound synchronisation then overlaps

@@ -172,7 +172,7 @@ def test_mixed_batch(hjd, dec, golden):
         assert np.array_equal(o, orgb)
 
 
-@pytest.mark.parametrize("bits", [64, 128, 256, 512, 1024, 4096])
+@pytest.mark.parametrize("bits", [64, 128, 256, 512, 1024, 4096, 16384])
 def test_subsequence_sizes(hjd, bits, golden):
     """The subsequence length is a tuning knob only: output must not depend on it."""
     d = hjd.Decoder(0, subseq_bits=bits)

@@ -52,7 +52,7 @@ SHAPES = [(1, 1, 1, 1), (17, 9, 2, 2), (4099, 9, 2, 2), (8192, 16, 2, 2), (7, 30
           (3840, 2160, 2, 2), (1920, 1080, 2, 2), (65535, 8, 1, 1)]
 
 
-@pytest.mark.parametrize("S", [64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("S", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_no_kernel_can_leave_its_slab(hjd, header, S):
     _, jd = header
     for (w, h, hf, vf), bpp, overlap, rst, fmt in itertools.product(SHAPES, (0.05, 1.35, 6.0), (0, -1, 3), (0, 5), (0, 1)):
@@ -78,23 +78,25 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         Q = T_ - K
         assert K < T_ and o.nsyncwg * Q >= nsub          # k_sync: workgroup w owns [w*Q, (w+1)*Q)
         assert o.nrepwg * T_ >= nsub                     # k_repair
-        assert o.nwritewg * WW >= nsub                   # k_write, k_scan
-        assert o.nwritewg <= o.wgsum_entries
-        assert (T_ // WW) * (o.nrepwg - 1) < o.nwritewg + 1   # k_repair_totals writes wgsum[R*wg + h] only below nwritewg (guarded)
+        nph = wps // o.phase_words
+        assert o.nwritewg * WW >= nsub * nph             # k_write, k_scan: one lane per staging window
+        assert o.nwritewg <= o.wgsum_entries             # k_repair_totals writes wgsum[wg * (T * nph / WW) + h] only below nwritewg (guarded)
+        assert WW % nph == 0 and T_ % (WW // nph) == 0   # a final-pass workgroup covers whole subsequences, a repair workgroup whole final-pass workgroups
         # --- LDS of the entropy kernels: tables, state arrays, then one window of phase_words + 2 words per lane
         assert o.lds_state_word_sync >= o.lds_state_word and o.lds_bytes_sync >= (o.lds_state_word_sync + 7 * T_ + 32 + (T_ // 64) * (o.phase_words + 2) * 64) * 4
         assert o.lds_bytes_write >= (o.lds_state_word + 64 + (WW // 64) * (o.phase_words + 2) * 64) * 4
         assert o.lds_bytes_sync <= 160 * 1024 and o.lds_bytes_write <= 160 * 1024
-        # --- checkpoints: k_sync workgroup w touches ckpt[(w * nph + ph) * T + slot], ph < nph = wps / phase_words, slot < T
-        nph = wps // o.phase_words
-        assert ((o.nsyncwg - 1) * nph + (nph - 1)) * T_ + (T_ - 1) < o.ckpt_entries
+        # --- checkpoints: canonical entry (ph, i) of the (only) image at ph * nsub_cap + i; k_sync workgroup w's scratch
+        #     entries at nsub_cap * nph + (w * nph + ph) * K + slot, slot < K
+        assert (nph - 1) * nsub + nsub - 1 < nsub * nph <= o.ckpt_entries
+        assert nsub * nph + ((o.nsyncwg - 1) * nph + nph - 1) * K + max(K, 1) - 1 < o.ckpt_entries
         # --- blocks: k_write stores blk[b] for b <= nblocks (closing entry); the IDCT kernel loads blk[b0 + tid], tid <= KB,
         #     and dca[b0 + tid], tid < KB, for the last group of the last MCU row: b0 + KB == nblocks
         assert o.nblocks == mcus * o.nb and o.nb == hf * vf + 2
         assert o.nblocks + 1 <= o.blk_entries and o.nblocks <= o.dca_entries
         # --- records: every store and every 16-byte load is guarded by rec_cap; the slab holds one burst more
         assert o.rec_cap % o.rec_run == 0 and o.rec_cap + o.rec_run <= o.rec_entries
-        assert o.rec_cap >= min(o.nblocks * 63, scan_len * 8 // 2)   # a record costs at least two scan bits
+        assert o.rec_cap >= min(o.nblocks * 63, scan_len * 8 // 2) + o.rec_run * nsub * nph   # a record costs at least two scan bits; every window's run is padded
         # --- DC chunks cover every MCU; dcsum holds three sums per chunk
         assert o.ndcchunk * o.dc_chunk >= mcus and 3 * o.ndcchunk <= o.dcsum_entries
         # --- IDCT groups: groups_per_row * mcuy workgroups of <= group_mcus MCUs
