@@ -14,10 +14,10 @@
 //              slot = u*8+v is the coefficient's place after DeZigZag + TransformArray (loadjpg.cpp:156-180), u the
 //              horizontal frequency; all ones = padding), every subsequence's run rounded up to HJD_REC_RUN
 //              records so that it is written in aligned 16-byte stores
-//   blk      : one uint4 per block: x = index of the block's first record, y = the decoded DC difference
-//              (k_write), z/w = 64-bit mask of the slots its AC records fill (those decoded in the subsequence that
-//              holds its DC symbol; later ones are flagged in the record); one extra entry per image closes the
-//              last block's record range
+//   blk      : one uint4 per block: x = index of the block's first record, y = the decoded DC difference, z/w = 64-bit mask of
+//              the slots its AC records fill (those decoded by the k_write lane that holds its DC symbol; later ones are flagged
+//              in the record and added by the back end); one extra entry per image closes the last block's record range
+//   dcd      : per block, the DC difference once more as int16 (what the DC prediction kernels read)
 //   dca      : per block, the DC value after prediction (int16), written by k_dcapply
 //   wgmap    : for every kernel's workgroup numbering, workgroup -> image (one load instead of a search)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
@@ -151,5 +151,5 @@ struct HjdImageState {
 // synchronisation record of one subsequence (substate[]): x = end state bit position (>= end of the
 // subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
-#define HJD_REC_ORPHAN (1u << 29) // the record's block began in an earlier subsequence: its slot is not in the block's mask
+#define HJD_REC_ORPHAN (1u << 29) // the record's block began in an earlier k_write span: its slot is not in the block's mask
 #define HJD_REC_RUN 4 // records per aligned 16-byte store: every subsequence's run is padded to a multiple

@@ -137,6 +137,7 @@ struct WriteCtx {
     uint32_t *rec;
     uint32_t rec_cap;
     uint4 *blk;
+    int16_t *dcd;           // per block: the DC difference again, compact, for the DC prediction kernels (2 bytes per block instead of a 16-byte entry)
     uint32_t nblocks;
     const uint8_t *slot_of; // LDS: zig-zag index -> slot u*8+v
     unsigned long long mask; // slots filled by the records of the block in progress (this subsequence's part of it)
@@ -145,8 +146,12 @@ struct WriteCtx {
     uint32_t tag;           // block bits of a record: (block & 127) << 22, | HJD_REC_ORPHAN while the block began elsewhere
 };
 
-// The entry of block b once its last symbol is decoded (or, from the caller, when the subsequence ends inside
-// it): written by the lane that decoded the block's DC symbol (bfirst != ~0), one 16-byte store.
+// The entry of block b = (first record, DC difference, 64-bit mask of the slots its records fill), written once and whole by
+// the lane that decoded the block's DC symbol (bfirst != ~0), when the block ends or the lane's span does.  Records of a block
+// that began in an earlier span (one block in five straddles at 512-bit spans) are marked HJD_REC_ORPHAN instead: the back end
+// adds their slots to the block's mask itself before it builds its term lists.  (Global atomics into the entry from the lanes
+// that decode a straddling block's later parts were tried: k_write 15 % slower, against one cheap extra pass over the
+// records in the back end.)
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
     if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint4(W.bfirst, W.bdc, (uint32_t)W.mask, (uint32_t)(W.mask >> 32));
@@ -154,23 +159,14 @@ __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
     W.mask = 0ull;
 }
 
-// Decode symbols from state (p,z,m) until p >= end.  One symbol per iteration.
-//   WRITE = false: nblk counts blocks completed, nrec the AC records they hold      (synchronisation)
-//   WRITE = true : nblk is the absolute block index, nrec the index of the next record.  Every non-zero
-//                  AC coefficient becomes one record (value | slot << 16 | block << 22: the DCT[] array of
-//                  loadjpg.cpp:499-863 in sparse form, already at its place after DeZigZag/TransformArray);
-//                  blk[b] = (first record of block b, DC DIFFERENCE, mask of the slots filled) — DC
-//                  prediction (loadjpg.cpp:619-667) is a prefix sum done by k_dcsum/k_dcapply.  The entry
-//                  is written, once and whole, by the lane that decodes the block's DC symbol.  Records of
-//                  a block that began in an earlier subsequence (about one block in 18 straddles) are
-//                  marked HJD_REC_ORPHAN instead: the IDCT kernel adds their slots to the mask itself.
-// `rowp` points at the staged window of the lane's row, `row_bit0` is the absolute bit position of the
-// window's first bit.  tabY/tabCb/tabCr: byte offsets of the component's (DC | AC << 16) primary tables.
-template <bool WRITE, bool RESTART>
-__device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0,
-                                            uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb,
-                                            uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end, uint32_t pair_lim, uint32_t &nblk,
-                                            uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
+// Synchronisation form of the decode loop: symbols from state (p, z, m) until p >= end; nblk counts blocks completed, nrec the
+// AC records they hold; no values are extracted.  `rowp` points at the staged window of the lane's row, `row_bit0` is the
+// absolute bit position of the window's first bit.  tabY/tabCb/tabCr: byte offsets of the component's (DC | AC << 16)
+// primary tables.
+template <bool RESTART>
+__device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+                                          uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                          uint32_t end, uint32_t pair_lim, uint32_t &nblk, uint32_t &nrec, RestartCtx &rc)
 {
     ReaderLds rd;
     rd.init(rowp, p - row_bit0);
@@ -185,85 +181,40 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
-    while (p < end && (!WRITE || nblk < W.nblocks)) {
+    while (p < end) {
         rd.prefetch();
         const uint32_t win = rd.window();
-        uint32_t e;
-        if (WRITE) {
-            e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
-        } else {
-            // synchronisation form: [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The
-            // pair is taken while the first symbol cannot end the block (an AC advance is at most 16) and the second
-            // still starts inside the subsequence (a step is at most 31 bits): the states passed on are then exactly
-            // those of the symbol-by-symbol walk of the final pass.
-            const uint16_t *ep = reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
-            const uint32_t e1 = ep[0], e2 = ep[1];
-            // restart streams: only while the next marker is more than a step (31 bits) plus the 8 bits of the rules' look-ahead
-            // away, so that no marker rule could have fired at the boundary the pair steps over
-            e = (z < 48u && p < pair_lim && (!RESTART || p + 40u < mnext)) ? e2 : e1;
-        }
+        // [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The pair is taken while the first
+        // symbol cannot end the block (an AC advance is at most 16) and the second still starts inside the window (a step
+        // is at most 31 bits): the states passed on are then exactly those of the symbol-by-symbol walk of the final pass.
+        const uint16_t *ep = reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
+        const uint32_t e1 = ep[0], e2 = ep[1];
+        // restart streams: only while the next marker is more than a step (31 bits) plus the 8 bits of the rules' look-ahead
+        // away, so that no marker rule could have fired at the boundary the pair steps over
+        uint32_t e = (z < 48u && p < pair_lim && (!RESTART || p + 40u < mnext)) ? e2 : e1;
         if ((e & 31u) == 0u) {
             // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
             // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
             const uint32_t sub = e >> 5;
             e = sub ? L.sec[(sub - 1u) * HJD_SEC_SIZE + ((win >> 16) & (HJD_SEC_SIZE - 1u))] : 0u;
-            if ((e & 31u) == 0u) {
-                if (WRITE) flags |= HJD_FLAG_BAD_CODE;
-                e = 16u; // skip 16 bits: any progress will do, the result is discarded or flagged
-            }
+            if ((e & 31u) == 0u) e = 16u; // skip 16 bits: any progress will do, the final pass flags it
         }
-        // WRITE: e = length | value bits << 5 | advance << 9.  Synchronisation: e = (length + value bits) | advance << 5 | record << 12.
-        const uint32_t len = e & 31u, s = WRITE ? (e >> 5) & 15u : 0u, adv = WRITE ? e >> 9 : (e >> 5) & 127u;
+        // e = (length + value bits) | advance << 5 | records << 14
+        const uint32_t tot = e & 31u, adv = (e >> 5) & 127u;
         const bool isdc = z == 0u;
-        if (WRITE) {
-            // value bits + DetermineSign (loadjpg.cpp:396-409): v < 2^(s-1), i.e. leading value bit 0, means v - (2^s - 1)
-            const uint32_t t = win << len;
-            const uint32_t vb = (t >> 1) >> (31u - s);
-            const int val = (int)vb - (int)(~(uint32_t)((int)t >> 31) & ((1u << s) - 1u));
-            if (isdc) {
-                W.bfirst = nrec;
-                W.bdc = (uint32_t)(int)(int16_t)val;
-                W.tag = (nblk & 127u) << 22;
-                // the reference looks for a marker again between the DC code and its extra bits
-                if (RESTART && !rc.conf && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
-            } else if (s != 0u) { // AC run/size: loadjpg.cpp:776-808
-                const uint32_t zw = z + adv - 1u;
-                const uint32_t slot = W.slot_of[zw & 63u];
-                uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag;
-                if (zw > 63u) {
-                    flags |= HJD_FLAG_OVERRUN;
-                    w = HJD_REC_PAD;
-                } else {
-                    W.mask |= 1ull << slot;
-                }
-                W.r0 = W.r1;
-                W.r1 = W.r2;
-                W.r2 = W.r3;
-                W.r3 = w;
-                if ((nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u) {
-                    if (nrec < W.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - (HJD_REC_RUN - 1u))) = make_uint4(W.r0, W.r1, W.r2, W.r3);
-                    else flags |= HJD_FLAG_OVERRUN;
-                }
-                nrec++;
-            }
-        } else {
-            nrec += e >> 14;
-        }
+        nrec += e >> 14;
         z += adv;
         tb = isdc ? pair >> 16 : tb;
         const bool blk_end = z >= 64u;
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
-            if (WRITE) write_block_entry(W, nblk);
             nblk++;
-            if (WRITE && nblk == W.nblocks) W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
             m = mnx;
             pair = nxt.x;
             mnx = nxt.y;
             nxt = L.mt[mnx];
             tb = pair & 0xFFFFu;
         }
-        const uint32_t tot = len + s;
         p += tot;
         rd.advance(tot);
         if (RESTART && rc.conf) {
@@ -289,9 +240,135 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 rd.init(rowp, p - row_bit0);
             }
         } else if (RESTART) {
-            if (WRITE && blk_end) rc.left--;
+            if ((blk_end && p + 8u > mnext) || p > mnext) { // pulled back onto the next interval start
+                p = mnext;
+                z = 0u;
+                m = 0u;
+                pair = tabY;
+                mnx = L.mt[0].y;
+                nxt = L.mt[mnx];
+                tb = pair & 0xFFFFu;
+                rc.mk++;
+                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                if (p >= end) break; // the next window is staged by the caller
+                rd.init(rowp, p - row_bit0);
+            }
+        }
+    }
+}
+
+// The final pass over one staging window: decode symbols from state (p, z, m) until p >= end, one symbol per iteration, and
+// write the coefficients out (output format: WriteCtx, hjd_device.h).  nblk = absolute block index, nrec = index of the next
+// record.  Everything a DC symbol does is predicated (selects) instead of branched: some lane of a wave is at a DC symbol, at
+// an end of block and at an AC coefficient in nearly every iteration, so every branch region is executed by every wave anyway
+// (round 2's loop: ~90 vector instructions per iteration, a third of them moves and mask juggling around the regions).
+template <bool RESTART>
+__device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+                                           uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                           uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
+{
+    ReaderLds rd;
+    rd.init(rowp, p - row_bit0);
+    uint32_t mnext = 0xFFFFFFFFu;
+    if (RESTART) {
+        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
+        mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+    }
+    uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
+    uint32_t mnx = (m + 1u == nb) ? 0u : m + 1u;
+    uint2 nxt = L.mt[mnx]; // the NEXT block's table pair and successor, fetched a block ahead
+    uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
+    const char *lutb = reinterpret_cast<const char *>(L.lut);
+
+    while (p < end) {
+        rd.prefetch();
+        const uint32_t win = rd.window();
+        uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
+        if ((e & 31u) == 0u) {
+            // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
+            // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
+            const uint32_t sub = e >> 5;
+            e = sub ? L.sec[(sub - 1u) * HJD_SEC_SIZE + ((win >> 16) & (HJD_SEC_SIZE - 1u))] : 0u;
+            if ((e & 31u) == 0u) {
+                flags |= HJD_FLAG_BAD_CODE;
+                e = 16u; // skip 16 bits: any progress will do, the result is flagged
+            }
+        }
+        // e = length | value bits << 5 | advance << 9
+        const uint32_t len = e & 31u, s = (e >> 5) & 15u, adv = e >> 9;
+        // value bits + DetermineSign (loadjpg.cpp:396-409): v < 2^(s-1), i.e. leading value bit 0, means v - (2^s - 1)
+        const uint32_t t = win << len;
+        const uint32_t vb = (t >> 1) >> (31u - s);
+        const int val = (int)vb - (int)(~(uint32_t)((int)t >> 31) & ((1u << s) - 1u));
+        const bool isdc = z == 0u;
+        // DC symbol (loadjpg.cpp:562-667): the block's entry begins here
+        W.bfirst = isdc ? nrec : W.bfirst;
+        W.bdc = isdc ? (uint32_t)(int)(int16_t)val : W.bdc;
+        W.tag = isdc ? (nblk & 127u) << 22 : W.tag;
+        if (isdc) W.dcd[nblk] = (int16_t)val;
+        // the reference looks for a marker again between the DC code and its extra bits
+        if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
+        const uint32_t zw = z + adv - 1u;
+        if (!isdc && s != 0u) { // AC run/size: loadjpg.cpp:776-808
+            const bool over = zw > 63u;
+            const uint32_t slot = W.slot_of[zw & 63u];
+            const uint32_t w = over ? HJD_REC_PAD : (((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag);
+            flags |= over ? HJD_FLAG_OVERRUN : 0u;
+            W.mask |= over ? 0ull : 1ull << slot;
+            W.r0 = W.r1;
+            W.r1 = W.r2;
+            W.r2 = W.r3;
+            W.r3 = w;
+            const bool burst = (nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u;
+            flags |= (burst && nrec >= W.rec_cap) ? HJD_FLAG_OVERRUN : 0u;
+            if (burst && nrec < W.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - (HJD_REC_RUN - 1u))) = make_uint4(W.r0, W.r1, W.r2, W.r3);
+            nrec++;
+        }
+        z += adv;
+        tb = isdc ? pair >> 16 : tb;
+        const bool blk_end = z >= 64u;
+        const uint32_t tot = len + s;
+        p += tot;
+        rd.advance(tot);
+        if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
+            z = 0u;
+            write_block_entry(W, nblk);
+            nblk++;
+            if (nblk == W.nblocks) {
+                W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
+                end = p;                                    // the image is complete: what follows is not looked at
+            }
+            m = mnx;
+            pair = nxt.x;
+            mnx = nxt.y;
+            nxt = L.mt[mnx];
+            tb = pair & 0xFFFFu;
+        }
+        if (RESTART && rc.conf) {
+            // Conformant mode (never the default): ITU T.81 B.2.4.1 / F.1.2.3 — an interval ends where nothing but
+            // padding (1-bits up to the byte boundary) separates the end of a block from the marker.
+            bool jump = p > mnext;
+            if (blk_end && !jump) {
+                const uint32_t d = mnext - p;
+                if (d < 8u) jump = d == 0u || (rd.window() >> (32u - d)) == (1u << d) - 1u;
+            }
+            if (jump) {
+                p = mnext;
+                z = 0u;
+                m = 0u;
+                pair = tabY;
+                mnx = L.mt[0].y;
+                nxt = L.mt[mnx];
+                tb = pair & 0xFFFFu;
+                rc.mk++;
+                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                if (p >= end) break;
+                rd.init(rowp, p - row_bit0);
+            }
+        } else if (RESTART) {
+            if (blk_end) rc.left--;
             if ((blk_end && p + 8u > mnext) || p > mnext) {
-                if (WRITE && nblk < W.nblocks) {
+                if (nblk < W.nblocks) {
                     // clean only if a whole interval of whole MCUs ends exactly here
                     const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
                     if (!clean) flags |= HJD_FLAG_DIRTY;
@@ -308,7 +385,7 @@ __device__ __forceinline__ void decode_span(const EntropyLds &L, const uint32_t 
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
                 if (p >= end) break; // the next window is staged by the caller
                 rd.init(rowp, p - row_bit0);
-            } else if (WRITE && blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < W.nblocks) {
+            } else if (blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < W.nblocks) {
                 flags |= HJD_FLAG_DIRTY; // an interval ends here but the marker is not where the reference looks
                 rc.left = rc.ri_blocks;
             }
@@ -339,8 +416,6 @@ __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, ui
     const uint32_t sp = i * S;
     const uint32_t end = min(sp + S, E.total_bits);
     RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
-    uint32_t flags = 0;
-    WriteCtx W = {};
     if (im.restart && active) {
         rc.nmark = E.nmark;
         uint32_t lo = 0, hi = rc.nmark; // first marker past the start of this row
@@ -365,8 +440,8 @@ __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, ui
         if (go) {
             const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
             for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-            if (im.restart) decode_span<false, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
-            else decode_span<false, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+            if (im.restart) sync_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
+            else sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
         }
         after_phase(ph);
     }
@@ -397,9 +472,9 @@ __device__ __forceinline__ void decode_window_write(const RowEnv &E, bool active
             else hi = mid;
         }
         rc.mk = lo;
-        decode_span<true, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, 0u, nblk, nrec, W, flags, rc);
+        write_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
     } else {
-        decode_span<true, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, 0u, nblk, nrec, W, flags, rc);
+        write_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -419,8 +494,6 @@ __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, 
     const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u; // as in decode_row
     if (!(active && p < pend)) return;
     RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
-    uint32_t flags = 0;
-    WriteCtx W = {};
     const uint32_t *src = row_base(E.wbase, i, lw) + (size_t)ph * WPP * 64u;
     for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
     if (im.restart) {
@@ -432,9 +505,9 @@ __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, 
             else hi = mid;
         }
         rc.mk = lo;
-        decode_span<false, true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+        sync_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
     } else {
-        decode_span<false, false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, W, flags, rc);
+        sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
     }
 }
 
@@ -446,6 +519,23 @@ __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, 
 //         tables are even loaded) when every start state already equals its predecessor's end.
 // MODE 2: MODE 1 for the last repair launch, which also leaves the block / record totals of the final-pass
 //         workgroups it covers (k_scan's job when no repair launch is configured).
+
+// Blocks and records (each k_write lane's run rounded up to whole bursts) of one subsequence, from its checkpoints; a k_write
+// lane covers P.write_windows consecutive staging windows.  ckp(ph) = checkpoint word y of window ph.
+template <class CkY>
+__device__ __forceinline__ void subseq_totals(uint32_t nph, uint32_t ww, CkY cky, uint32_t &sb, uint32_t &sr)
+{
+    sb = sr = 0;
+    for (uint32_t ph = 0; ph < nph; ph += ww) {
+        uint32_t r = 0;
+        for (uint32_t w = 0; w < ww; w++) {
+            const uint32_t c = cky(ph + w);
+            sb += (c >> 9) & 2047u;
+            r += c >> 20;
+        }
+        sr += (r + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
+    }
+}
 
 // Synchronisation, MODE 0 (k_sync).
 // Round 0: every lane first decodes the last P.lane_warm staging windows of the subsequence BEFORE its own from a guess (a
@@ -704,24 +794,20 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     if (MODE == 0) {
         // Totals of the final-pass workgroups: k_write runs one lane per staging WINDOW and places its outputs by prefix
         // sums over the windows' block / record counts; the sums over everything BEFORE a final-pass workgroup come from
-        // per-workgroup totals (P.wgsum, zeroed by k_unstuff_count).  A final-pass workgroup covers G = HJD_WRITE_WG / nph
+        // per-workgroup totals (P.wgsum, zeroed by k_unstuff_count).  A final-pass workgroup covers G
         // subsequences, which a synchronisation workgroup's range [own0, own1) cuts anywhere: LDS atomics per group, then one
         // global atomic per group and counter.  (Round 2 left this to a launch of its own — a 512-lane, 60 KB-LDS gate that
         // sat 0.2 ms waiting for a CU beside the other streams' kernels.  A stale workgroup border is still caught: k_write
         // checks the induction step for every subsequence and the host re-synchronises.)
-        const uint32_t G = HJD_WRITE_WG / nph; // nph is a power of two <= 64
+        const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows); // subsequences per final-pass workgroup (powers of two)
         const uint32_t wq0 = own0 / G;
         __syncthreads(); // everyone is done with the work list
         s_lp[tid] = 0u;
         s_lst[tid] = 0u;
         __syncthreads();
         if (owned) {
-            uint32_t sb = 0, sr = 0;
-            for (uint32_t ph = 0; ph < nph; ph++) {
-                const uint32_t c = ck(ph, tid)->y;
-                sb += (c >> 9) & 2047u;
-                sr += ((c >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
-            }
+            uint32_t sb, sr;
+            subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, tid)->y; }, sb, sr);
             atomicAdd(&s_lp[i / G - wq0], sb);
             atomicAdd(&s_lst[i / G - wq0], sr);
         }
@@ -735,14 +821,9 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     }
     if (MODE == 2) {
         // The same totals after a repair (host re-synchronisation): written, not added — a repair workgroup holds whole groups.
-        const uint32_t G = HJD_WRITE_WG / nph;
+        const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows);
         uint32_t sb = 0, sr = 0;
-        if (valid)
-            for (uint32_t ph = 0; ph < nph; ph++) {
-                const uint32_t c = ck(ph, tid)->y;
-                sb += (c >> 9) & 2047u;
-                sr += ((c >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
-            }
+        if (valid) subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, tid)->y; }, sb, sr);
         const uint32_t ib = wave_incl_scan(sb), ir = wave_incl_scan(sr);
         __syncthreads(); // everyone is done with the work list
         s_lp[tid] = ib;
@@ -784,9 +865,10 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair_totals(HjdParams P) { sy
 
 // ---- stage 3: final entropy decode, coefficients out ------------------------------------------
 
-// One lane per staging WINDOW of a subsequence (256 bits by default): k_sync's checkpoints hold the decoder state at every
+// One lane per span of P.write_windows staging windows of a subsequence: k_sync's checkpoints hold the decoder state at every
 // window's end and the blocks / records decoded inside every window, so the final pass can start anywhere a window starts.
-// (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.)
+// (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.
+// Short spans mean short chains but also lanes that wait for the longest of the 64 spans of their wave.)
 __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -806,19 +888,27 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits, nph = (S >> 5) / P.phase_words;
+    const uint32_t WWN = P.write_windows, nu = nph / WWN; // windows per lane, lanes per subsequence
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    if (wg * HJD_WRITE_WG >= nsub * nph) return; // capacity-based grid: nothing in this workgroup
+    if (wg * HJD_WRITE_WG >= nsub * nu) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
 
-    const uint32_t u = wg * HJD_WRITE_WG + tid; // window number
-    const uint32_t i = u / nph, ph = u % nph;
+    const uint32_t u = wg * HJD_WRITE_WG + tid; // lane span number
+    const uint32_t i = u / nu, ph = (u % nu) * WWN; // subsequence, first window
     const bool valid = i < nsub;
     const uint32_t g = im.sub0 + i;
     const uint2 *ckc = P.ckpt + (size_t)im.sub0 * nph; // [window][subsequence] of this image
-    const uint2 mine = valid ? ckc[(size_t)ph * im.nsub_cap + i] : make_uint2(0u, 0u);
+    uint2 mine = make_uint2(0u, 0u); // x, y & 511: state at the end of the span; blocks and records inside it
+    uint32_t my_blocks = 0, my_recs = 0;
+    if (valid)
+        for (uint32_t w = 0; w < WWN; w++) {
+            mine = ckc[(size_t)(ph + w) * im.nsub_cap + i];
+            my_blocks += (mine.y >> 9) & 2047u;
+            my_recs += mine.y >> 20;
+        }
 
     // where this window's blocks and records go: totals of the workgroups before this one + scan inside
     uint32_t pb = 0, pr = 0;
@@ -830,10 +920,10 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t base_b, base_r, tot_b, tot_r;
     block_excl_scan(pb, s_w, &base_b);
     block_excl_scan(pr, s_w, &base_r);
-    uint32_t blk = base_b + block_excl_scan((mine.y >> 9) & 2047u, s_w, &tot_b);
-    uint32_t nrec = base_r + block_excl_scan(((mine.y >> 20) + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
+    uint32_t blk = base_b + block_excl_scan(my_blocks, s_w, &tot_b);
+    uint32_t nrec = base_r + block_excl_scan((my_recs + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
     uint32_t flags = 0;
-    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub * nph) { // the workgroup that holds the last window
+    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub * nu) { // the workgroup that holds the last span
         P.st[ii].total_blocks = base_b + tot_b;
         if (base_b + tot_b < im.nblocks) flags |= HJD_FLAG_SHORT;
     }
@@ -878,18 +968,20 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     }
     __syncthreads(); // tables are in LDS
 
-    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks,
-                  s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
-    W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun elsewhere
-    const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
+    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
+                  im.nblocks, s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
+    W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
-    decode_window_write(E, go, i, ph, p, z, m, blk, nrec, W, flags, left0);
-    // the window must end in the state, and with the record count, its checkpoint holds (else the places of everything
-    // after it are wrong: the host re-synchronises) — unless the image was complete before the window's end
+    for (uint32_t w = 0; w < WWN; w++) {
+        const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
+        decode_window_write(E, go, i, ph + w, p, z, m, blk, nrec, W, flags, left0);
+    }
+    // the span must end in the state, and with the record count, its checkpoints hold (else the places of everything
+    // after it are wrong: the host re-synchronises) — unless the image was complete before the span's end
     if (go && blk < im.nblocks && !(flags & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN)) &&
-        (p != mine.x || (z | (m << 6)) != (mine.y & 511u) || nrec - nrec0 != (mine.y >> 20)))
+        (p != mine.x || (z | (m << 6)) != (mine.y & 511u) || nrec - nrec0 != my_recs))
         flags |= HJD_FLAG_NOT_CONVERGED;
-    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the window ends inside a block
+    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the span ends inside a block it owns
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
         for (uint32_t q = k; q < HJD_REC_RUN; q++) {

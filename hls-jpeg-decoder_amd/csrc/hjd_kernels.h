@@ -25,6 +25,7 @@ struct HjdParams {
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
     uint4 *blk;                // per block: first record index, DC difference, slot mask lo, hi
+    int16_t *dcd;              // per block: DC difference as decoded (k_write)
     int16_t *dca;              // per block: DC value after prediction
     // workgroup -> image for every kernel's workgroup numbering (global numbers, like the off_* below)
     const uint32_t *map_chunk, *map_syncwg, *map_repwg, *map_writewg, *map_dcchunk;
@@ -41,6 +42,7 @@ struct HjdParams {
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
     uint32_t phase_words;      // words of a subsequence staged in LDS at a time (power of two, <= subseq_bits / 32)
+    uint32_t write_windows;    // staging windows one k_write lane decodes (power of two, <= windows per subsequence)
     uint32_t lane_warm;        // k_sync round 0: staging windows of the previous subsequence every lane decodes as warm-up
     uint32_t lds_sec_word;     // entropy kernels' dynamic LDS: word offset of the secondary tables
     uint32_t lds_state_word;   //                               word offset of the per-workgroup state arrays

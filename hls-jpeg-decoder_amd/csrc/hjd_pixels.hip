@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
         s_cos[tid] = conf ? c_cos_true[(tid & 7) * 8 + (tid >> 3)] : c_cos[(tid & 7) * 8 + (tid >> 3)];
         // C(u)*C(v): fl(C0*C0) = 0x1.fffffep-2 (not 0.5), C0 = 1/sqrtf(2) = 0x1.6a09e6p-1 (loadjpg.cpp:96-102,120)
         const uint32_t u = tid >> 3, v = tid & 7;
-        s_kk[tid] = (u == 0) ? (v == 0 ? (conf ? 0.5f : 0x1.fffffep-2f) : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f);
+        // ... times the 0.25 of loadjpg.cpp:123: scaling by a power of two commutes with every fp32 rounding of the sum (no
+        // term comes near the denormals), so the accumulators hold 0.25 * sum exactly and the final multiplication is gone
+        s_kk[tid] = 0.25f * ((u == 0) ? (v == 0 ? (conf ? 0.5f : 0x1.fffffep-2f) : 0x1.6a09e6p-1f) : (v == 0 ? 0x1.6a09e6p-1f : 1.0f));
     }
     if (tid < 48) reinterpret_cast<uint32_t *>(&s_qt[0][0])[tid] = reinterpret_cast<const uint32_t *>(&im.qt[0][0])[tid];
     if (tid >= 64 && tid < 128) s_hist[tid - 64] = 0u;
@@ -390,16 +392,13 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
                     }
                 }
             }
-            // (int)(0.25*sum), then short += 128, then Clamp (loadjpg.cpp:123,136-137,219).  The short only wraps
+            // (int)(0.25*sum) — the accumulators hold 0.25*sum — then short += 128, then Clamp (loadjpg.cpp:123,136-137,219).  The short only wraps
             // for |0.25*sum| >= 32640; below that Clamp((short)((int)t + 128)) == saturate_u8(trunc(t) + 128),
             // which is what v_cvt_pk_u8_f32 computes from the integral float trunc(t) + 128 (exact below 2^23).
-            float big = 0.0f;
+            float big = 0.0f; // max |.| over the 16 values: one v_max3_f32 with |.| source modifiers per pair (the compiler spends
+                              // three instructions on fmaxf(fabsf(a), fabsf(b)))
 #pragma unroll
-            for (int y = 0; y < 8; y++) {
-                acc0[y] = acc0[y] * 0.25f;
-                acc1[y] = acc1[y] * 0.25f;
-                big = fmaxf(big, fmaxf(fabsf(acc0[y]), fabsf(acc1[y])));
-            }
+            for (int y = 0; y < 8; y++) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(big) : "v"(acc0[y]), "v"(acc1[y]));
             if (conf) { // conformant mode: round to nearest
 #pragma unroll
                 for (int y = 0; y < 8; y++) {

@@ -73,6 +73,7 @@ struct hjd_decoder {
     std::mutex conc_mu;
     hipEvent_t conc_ev[16] = {};
     uint64_t conc_runs = 0;
+    uint32_t write_windows = 1; // staging windows one k_write lane decodes (HJD_WRITE_WINDOWS: tuning knob, power of two)
     int lane_warm = 0;         // k_sync round 0: warm-up windows per lane inside the previous subsequence; -1 = half a subsequence
                                // (HJD_LANE_WARM: tuning knob; measured: same work and four windows more latency than none)
     int stagger = 0;           // ranges of a batch run as a software pipeline (batch_enqueue): 0 off, 1 after sync, 2 after the final pass
@@ -135,7 +136,7 @@ struct hjd_batch {
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
     uint4 *d_blk = nullptr;
-    int16_t *d_dca = nullptr;
+    int16_t *d_dca = nullptr, *d_dcd = nullptr;
     uint32_t *d_rec = nullptr;
     uint32_t *d_maps = nullptr; // workgroup -> image tables of all kernels, one allocation
     // A batch object can be re-prepared in place (hjd_batch_reset): slabs are only re-allocated when the new
@@ -318,6 +319,8 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->conformant = opt->conformant ? 1 : 0;
     }
     if (const char *ew = getenv("HJD_LANE_WARM")) d->lane_warm = atoi(ew);
+    if (const char *ew = getenv("HJD_WRITE_WINDOWS"))
+        if (atoi(ew) >= 1 && atoi(ew) <= 64 && (atoi(ew) & (atoi(ew) - 1)) == 0) d->write_windows = (uint32_t)atoi(ew);
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
@@ -408,6 +411,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_blk);
     (void)hipFree(b->d_dca);
+    (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
     (void)hipFree(b->d_chunk_mark);
@@ -469,6 +473,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     uint32_t wpp = d->phase_words; // staging window of the entropy kernels, in words; k_write runs one lane per window
     if (wpp > S / 32) wpp = S / 32;
     const uint32_t nph = (S / 32) / wpp; // windows per subsequence
+    uint32_t wwn = d->write_windows;     // windows per k_write lane
+    if (wwn > nph) wwn = nph;
+    const uint32_t nu = nph / wwn;       // k_write lanes per subsequence
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, blk_cur = 0, rec_cur = 0, out_cur = 0;
@@ -525,7 +532,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.nrepwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
         b->nrepwg += im.nrepwg;
         im.writewg0 = b->nwritewg;
-        im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nph + HJD_WRITE_WG - 1) / HJD_WRITE_WG); // one lane per window
+        im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nu + HJD_WRITE_WG - 1) / HJD_WRITE_WG); // one lane per span of wwn windows
         b->nwritewg += im.nwritewg;
         im.dcchunk0 = b->ndcchunks;
         im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
@@ -567,7 +574,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             // With DRI the reference may leave the marker grid and finish its blocks on the zeros past the end of the
             // scan (sequential emulation, hjd_seq.hip): only the per-block bound holds there.
             const uint64_t bound = im.restart ? by_blocks : (by_blocks < by_bits ? by_blocks : by_bits);
-            const uint64_t cap = bound + (uint64_t)HJD_REC_RUN * im.nsub_cap * nph + 64; // every window's run ends in a whole burst
+            const uint64_t cap = bound + (uint64_t)HJD_REC_RUN * im.nsub_cap * nu + 64; // every k_write lane's run ends in a whole burst
             im.rec_cap = (uint32_t)(cap > 0xFFFFFF00ull ? 0xFFFFFF00ull : cap) & ~(uint32_t)(HJD_REC_RUN - 1);
         }
         im.rec_off = rec_cur;
@@ -603,6 +610,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     {   // dynamic LDS of the entropy kernels: primary and secondary tables, per-workgroup state, then one
         // staging window of phase_words + 2 words per lane
         P.phase_words = wpp;
+        P.write_windows = wwn;
         {   // warm-up inside the lanes of k_sync's round 0: half a subsequence unless told otherwise
             const uint32_t nph = (S / 32) / wpp;
             P.lane_warm = d->lane_warm < 0 ? nph / 2 : ((uint32_t)d->lane_warm > nph ? nph : (uint32_t)d->lane_warm);
@@ -636,9 +644,11 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint4) * (blk_cur + 1)));
     need(slab_reserve(b, b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
+    need(slab_reserve(b, b->d_dcd, sizeof(int16_t) * (blk_cur + 2)));
     need(slab_reserve(b, b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
     if (rcs != HJD_OK) return rcs;
     HIPCHK(hipMemsetAsync(b->d_blk, 0, sizeof(uint4) * (blk_cur + 1), up));
+    HIPCHK(hipMemsetAsync(b->d_dcd, 0, sizeof(int16_t) * (blk_cur + 2), up));
     std::vector<uint32_t> maps;
     {   // workgroup -> image for every kernel's workgroup numbering; IDCT groups also get their first block
         size_t off_chunk = 0, off_sync, off_rep, off_write, off_dc, off_group;
@@ -733,6 +743,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.rec = b->d_rec;
     P.blk = b->d_blk;
     P.dca = b->d_dca;
+    P.dcd = b->d_dcd;
     P.dcsum = b->d_dcsum;
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;

@@ -14,7 +14,7 @@ SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ
 SQ2="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"
 ONE="--streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end"
 if [ "$WHAT" = sq ] || [ "$WHAT" = all ]; then
-  for B in 16 32; do
+  for B in ${BATCHES:-16 32}; do
     rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $O/${TAG}_sq1_b$B -- python3 $R/bench.py --batch $B $ONE > $O/${TAG}_sq1_b$B.log 2>&1
     rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $O/${TAG}_sq2_b$B -- python3 $R/bench.py --batch $B $ONE > $O/${TAG}_sq2_b$B.log 2>&1
   done
