@@ -138,7 +138,7 @@ struct HjdImageState {
     uint32_t sync_decodes;  // diagnostics: subsequence decodes executed by the synchronisation launches
     uint32_t sync_iters_max;
     uint32_t nmarkers;      // restart mode: markers (FF xx, xx != 0) found inside the scan
-    uint32_t pad;
+    uint32_t emulated;      // 1: the sequential emulation (hjd_seq.hip) has decoded this image in this run
 };
 #define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)

@@ -163,8 +163,11 @@ __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 // AC records they hold; no values are extracted.  `rowp` points at the staged window of the lane's row, `row_bit0` is the
 // absolute bit position of the window's first bit.  tabY/tabCb/tabCr: byte offsets of the component's (DC | AC << 16)
 // primary tables.
+// RESTART = true is the loop that knows the reference's marker rules; it runs only while a marker is within reach of them
+// (p + 40 > the next marker's position: a step is at most 31 bits and the rules look 8 bits ahead) — sync_span hands the long
+// stretches between markers to the plain loop.
 template <bool RESTART>
-__device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+__device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
                                           uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                           uint32_t end, uint32_t pair_lim, uint32_t &nblk, uint32_t &nrec, RestartCtx &rc)
 {
@@ -181,7 +184,7 @@ __device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *_
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
-    while (p < end) {
+    while (p < end && (!RESTART || p + 40u > mnext)) {
         rd.prefetch();
         const uint32_t win = rd.window();
         // [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The pair is taken while the first
@@ -257,13 +260,36 @@ __device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *_
     }
 }
 
+template <bool RESTART>
+__device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+                                          uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                          uint32_t end, uint32_t pair_lim, uint32_t &nblk, uint32_t &nrec, RestartCtx &rc)
+{
+    if (!RESTART) {
+        sync_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, pair_lim, nblk, nrec, rc);
+        return;
+    }
+    // Restart streams (round 2 evaluated the marker rules at every step of every lane: 96 against 134 Gpixel/s): the plain loop
+    // up to 39 bits before the next marker, the loop with the rules around it.
+    while (p < end) {
+        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
+        const uint32_t mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+        if (p + 40u <= mnext) {
+            const uint32_t fend = min(end, mnext - 39u);
+            sync_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, fend, min(pair_lim, fend - 1u), nblk, nrec, rc); // pairs while p + 40 < mnext
+            if (p >= end) break;
+        }
+        sync_core<true>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, pair_lim, nblk, nrec, rc);
+    }
+}
+
 // The final pass over one staging window: decode symbols from state (p, z, m) until p >= end, one symbol per iteration, and
 // write the coefficients out (output format: WriteCtx, hjd_device.h).  nblk = absolute block index, nrec = index of the next
 // record.  Everything a DC symbol does is predicated (selects) instead of branched: some lane of a wave is at a DC symbol, at
 // an end of block and at an AC coefficient in nearly every iteration, so every branch region is executed by every wave anyway
 // (round 2's loop: ~90 vector instructions per iteration, a third of them moves and mask juggling around the regions).
 template <bool RESTART>
-__device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+__device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
@@ -280,7 +306,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
-    while (p < end) {
+    while (p < end && (!RESTART || p + 40u > mnext)) {
         rd.prefetch();
         const uint32_t win = rd.window();
         uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
@@ -390,6 +416,39 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
                 rc.left = rc.ri_blocks;
             }
         }
+    }
+}
+
+template <bool RESTART>
+__device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+                                           uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
+                                           uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
+{
+    if (!RESTART) {
+        write_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        return;
+    }
+    // see sync_span.  The plain loop keeps no count of the blocks left in the interval: it is brought up to date after it, and an
+    // interval that ended inside the stretch — no marker where the block count says one should be — is the same DIRTY
+    // verdict the loop with the rules gives (loadjpg.cpp:535-550 never fires there, the reference decodes on).
+    while (p < end && nblk < W.nblocks) {
+        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
+        const uint32_t mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+        if (p + 40u <= mnext) {
+            const uint32_t before = nblk;
+            write_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
+            const uint32_t done = nblk - before;
+            if (!rc.conf && rc.ri_blocks != 0u) {
+                if (done >= rc.left && before + rc.left < W.nblocks) {
+                    flags |= HJD_FLAG_DIRTY;
+                    rc.left = rc.ri_blocks - (done - rc.left) % rc.ri_blocks;
+                } else {
+                    rc.left -= done;
+                }
+            }
+            if (p >= end || nblk >= W.nblocks) break;
+        }
+        write_core<true>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
     }
 }
 

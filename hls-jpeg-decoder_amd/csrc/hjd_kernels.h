@@ -38,6 +38,8 @@ struct HjdParams {
     // added to blockIdx.x so that every kernel still sees batch-global workgroup / image numbers.
     uint32_t off_chunk, off_syncwg, off_repwg, off_writewg, off_img, off_dcchunk, off_group;
     uint32_t conformant;       // hjd_options.conformant: selects the conformant instantiation of the back end
+    uint32_t gate_emulated;    // k_idct_color: 1 = only images the sequential emulation has just decoded (HjdImageState::emulated)
+    const uint32_t *rst_list;  // device images that carry DRI, ascending (the sequential emulation's candidates)
     uint32_t subseq_bits;      // power of two, 64..4096
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
@@ -57,5 +59,5 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s);
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);
-int hjd_launch_seq_decode(const HjdParams &P, const uint32_t *d_list, uint32_t n, hipStream_t s); // images listed by index
+int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s); // candidates rst_list[first .. first + n): those flagged DIRTY are decoded
 int hjd_launch_color_table(uint8_t *d_out, hipStream_t s); // test hook: 3 << 24 bytes

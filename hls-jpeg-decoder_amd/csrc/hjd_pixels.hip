@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     const uint32_t bid = blockIdx.x + P.off_group;
     const uint2 gm = P.map_group[bid];
     const int ii = (int)gm.x;
+    if (P.gate_emulated && !P.st[ii].emulated) return; // second launch, after the sequential emulation: its images only
     const HjdImage &im = P.img[ii];
     const uint32_t lg = bid - im.group0;
     const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;

@@ -25,7 +25,34 @@ __constant__ uint8_t c_zz_to_slot_seq[64] = HJD_ZZ_TO_SLOT;
 struct SeqReader { // stHuffmanData::m_stream / stream_index / g_reservoir / g_nbits_in_reservoir (loadjpg.h:149-153)
     const uint8_t *s;
     uint32_t n, idx, res, nbits;
-    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i < n ? s[i] : 0u; }
+    // The scan is read through a 32-byte register window (two 16-byte loads, the second fetched 16 bytes before it is needed)
+    // instead of one dependent global load per byte: the lane's chain was mostly load latency (1080p: 120 ms).
+    uint32_t b0 = 0xFFFFFFE0u; // bytes [b0, b0 + 16) in w0, [b0 + 16, b0 + 32) in w1; the scan's slab is 16-byte aligned and padded
+    uint4 w0, w1;
+    __device__ __forceinline__ uint4 load16(uint32_t base) const
+    {
+        return base < n ? *reinterpret_cast<const uint4 *>(s + base) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __device__ __forceinline__ uint32_t at(uint32_t i)
+    {
+        if (i >= n) return 0u;
+        uint32_t q = i - b0;
+        if (q >= 32u) { // first access, or a resynchronisation jumped ahead
+            b0 = i & ~15u;
+            w0 = load16(b0);
+            w1 = load16(b0 + 16u);
+            q = i - b0;
+        } else if (q >= 24u) { // slide: keeps eight bytes behind the cursor (the look-ahead is one byte)
+            b0 += 16u;
+            w0 = w1;
+            w1 = load16(b0 + 16u);
+            q -= 16u;
+        }
+        const uint4 w = q < 16u ? w0 : w1;
+        const uint32_t k = (q >> 2) & 3u;
+        const uint32_t word = k == 0u ? w.x : (k == 1u ? w.y : (k == 2u ? w.z : w.w));
+        return (word >> ((q & 3u) * 8u)) & 0xFFu;
+    }
     __device__ __forceinline__ void fill(uint32_t limit) // FillNBits, live branch loadjpg.cpp:468-482
     {
         for (int k = 0; k < 2; k++)
@@ -52,7 +79,7 @@ struct SeqReader { // stHuffmanData::m_stream / stream_index / g_reservoir / g_n
         res &= (1u << nbits) - 1u;
         return v;
     }
-    __device__ __forceinline__ bool on_marker() const { return at(idx) == 0xFFu && at(idx + 1) != 0x00u; }
+    __device__ __forceinline__ bool on_marker() { return at(idx) == 0xFFu && at(idx + 1) != 0x00u; }
     __device__ __forceinline__ void resync() // :544-546 / :634-636
     {
         idx += 2;
@@ -75,13 +102,27 @@ __device__ __forceinline__ int seq_extend(uint32_t v, uint32_t n) // DetermineSi
     return v < (1u << (n - 1u)) ? (int)v - (int)((1u << n) - 1u) : (int)v;
 }
 
-__global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, const uint32_t *__restrict__ list)
+// One workgroup per image with DRI; it returns at once unless the parallel path has flagged the image (the launch is part of
+// every run of a batch that holds such images, on a side stream: no host round trip, no allocation — hjd_api.cpp).
+__global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
 {
-    if (threadIdx.x != 0) return;
-    const int ii = (int)list[blockIdx.x];
+    __shared__ HjdCanon s_canon[HJD_SLOTS]; // the code tables, out of LDS: the matching loop reads them three times per code length
+    const int ii = (int)P.rst_list[first + blockIdx.x];
+    if (!(P.st[ii].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER))) return; // whatever else the parallel path flagged after leaving
+                                                                            // the clean-resync domain means nothing
     const HjdImage &im = P.img[ii];
-    const HjdTableSet &ts = P.tabs[im.tabset];
-    SeqReader r = {P.raw + im.raw_off, im.scan_len, 0u, 0u, 0u}; // loadjpg.cpp:1148-1149
+    {
+        static_assert(sizeof(HjdCanon) % 4 == 0, "copied by words");
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&P.tabs[im.tabset].canon[0]);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&s_canon[0]);
+        for (uint32_t k = threadIdx.x; k < sizeof(s_canon) / 4u; k += 64u) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    SeqReader r;
+    r.s = P.raw + im.raw_off;
+    r.n = im.scan_len;
+    r.idx = r.res = r.nbits = 0u; // loadjpg.cpp:1148-1149
     uint32_t *rec = P.rec + im.rec_off;
     uint4 *blk = P.blk + im.blk_off;
     int16_t *dca = P.dca + im.blk_off;
@@ -92,7 +133,7 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, const uint32_t *
     for (uint32_t b = 0; b < im.nblocks && !flags; b++) {
         const uint32_t m = b % im.nb;
         const uint32_t comp = m < im.nby ? 0u : m - im.nby + 1u; // DecodeMCU order, :945-997
-        const HjdCanon &hdc = ts.canon[comp * 2], &hac = ts.canon[comp * 2 + 1];
+        const HjdCanon &hdc = s_canon[comp * 2], &hac = s_canon[comp * 2 + 1];
         const uint32_t first = nrec;
         uint32_t mlo = 0, mhi = 0, sym = 0;
 
@@ -160,14 +201,17 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, const uint32_t *
     }
     blk[im.nblocks] = make_uint4(min(nrec, im.rec_cap), 0u, 0u, 0u);
     HjdImageState &st = P.st[ii];
-    st.flags = flags; // replaces the parallel path's verdict (DIRTY) for this image
+    // replaces the parallel path's verdict for this image; what the unstuff stage found (BAD_MARKER) stays, because a host
+    // re-synchronisation re-runs everything after that stage and must send the image here again
+    st.flags = flags | (st.flags & HJD_FLAG_BAD_MARKER);
     st.total_blocks = flags ? 0u : im.nblocks;
+    st.emulated = 1u;
 }
 
-int hjd_launch_seq_decode(const HjdParams &P, const uint32_t *d_list, uint32_t n, hipStream_t s)
+int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_seq_decode, dim3(n), dim3(64), 0, s, P, d_list);
+    hipLaunchKernelGGL(k_seq_decode, dim3(n), dim3(64), 0, s, P, first);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -6,8 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,43 @@
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host side of a large batch: the header walks and the copy of the scan bytes into the pinned staging buffer
+// are independent per image.  One thread does 1024 x 1080p in ~35 ms (358 MB of memcpy) — several times the 9 ms of kernels it
+// feeds — so both loops are cut over a few host threads when there is enough to do (HJD_HOST_THREADS, default up to 8).
+static int host_threads()
+{
+    static int n = [] {
+        int v = (int)std::thread::hardware_concurrency();
+        if (v < 1) v = 1;
+        if (v > 8) v = 8;
+        if (const char *e = getenv("HJD_HOST_THREADS")) v = atoi(e) < 1 ? 1 : (atoi(e) > 64 ? 64 : atoi(e));
+        return v;
+    }();
+    return n;
+}
+
+template <class F>
+static void parallel_for(int n, size_t work_bytes, F f)
+{
+    int nt = host_threads();
+    if (work_bytes < ((size_t)4 << 20) || n < 2 * nt) nt = 1;
+    if (nt <= 1) {
+        for (int i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::atomic<int> next{0};
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&] {
+            for (;;) {
+                const int i0 = next.fetch_add(16);
+                if (i0 >= n) return;
+                for (int i = i0; i < n && i < i0 + 16; i++) f(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
 
 static const uint8_t kZzToSlot[64] = HJD_ZZ_TO_SLOT;
 
@@ -109,7 +148,7 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t chunk0, nchunk, syncwg0, nsyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
+    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
@@ -117,6 +156,13 @@ struct hjd_batch {
     hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
     int dirty_decodes = 0;           // images decoded by the sequential emulation kernel since prepare
+    // Restart streams outside the clean-resync domain: every run ends with a launch of k_seq_decode over the images that carry
+    // DRI (it returns at once for those the parallel path did not flag) and a gated launch of the back end, on a side stream
+    // that waits for the run and that hjd_batch_finish waits for.  Nothing is allocated and no host round trip is needed.
+    std::vector<uint32_t> rst_images; // device images with DRI, ascending
+    hipStream_t seq_stream = nullptr;
+    hipEvent_t seq_fork = nullptr, seq_done = nullptr;
+    bool seq_pending = false;
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
@@ -414,6 +460,9 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
+    if (b->seq_stream) (void)hipStreamDestroy(b->seq_stream);
+    if (b->seq_fork) (void)hipEventDestroy(b->seq_fork);
+    if (b->seq_done) (void)hipEventDestroy(b->seq_done);
     (void)hipFree(b->d_chunk_mark);
     (void)hipFree(b->d_mpos);
     (void)hipFree(b->d_mval);
@@ -457,13 +506,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     // Subsequence size: every lane of k_sync decodes one subsequence serially (k_write runs one lane per staging window whatever
     // the subsequence size), so a small batch wants short ones and a large batch long ones (fewer synchronisation
     // workgroups, tables loaded less often: 64 x 4K on four streams, 240 Gpixel/s at 2048 bits, 270 at 4096).  Unless the
-    // caller fixed it: the largest power of two that still leaves about 32768 subsequences, within 256..4096.
+    // caller fixed it: 4096 bits when that still leaves about 32768 subsequences, else 2048.
     uint32_t S = d->subseq_bits, K = d->sync_overlap;
     if (d->subseq_auto) {
         uint64_t bits = 0;
         for (int i = 0; i < b->n; i++)
             if (b->parse_status[i] == HJD_OK) bits += (uint64_t)parsed[i].stream_len * 8u;
-        S = 256;
+        S = 2048; // also for one image (3840x2160: 0.49 ms at 2048 bits, 0.70 ms at 256: short subsequences mean more refinement rounds)
         while (S < 4096 && (uint64_t)S * 2u * 32768u <= bits) S *= 2;
         if (d->overlap_auto) {
             const uint32_t k = 16384 / S;
@@ -595,6 +644,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->alg_bytes += (uint64_t)im.scan_len + j.header_bytes + (uint64_t)im.width * im.height * 3;
     }
     b->nimg = (int)b->img.size();
+    b->rst_images.clear();
+    for (int k = 0; k < b->nimg; k++)
+        if (b->img[k].restart) b->rst_images.push_back((uint32_t)k);
+    b->seq_pending = false;
     b->raw_bytes = raw_cur;
     b->ustream_bytes = us_cur;
     b->nblk_entries = blk_cur;
@@ -603,6 +656,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->state.assign(b->nimg, HjdImageState{});
     HjdParams &P = b->P;
     P.conformant = d->conformant ? 1u : 0u;
+    P.gate_emulated = 0u;
     P.subseq_bits = S;
     P.log2_words = 0;
     while ((32u << P.log2_words) < S) P.log2_words++;
@@ -667,6 +721,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         off_dc = fill(&HjdImage::dcchunk0, &HjdImage::ndcchunk);
         if (off_chunk == (size_t)-1 || off_sync == (size_t)-1 || off_rep == (size_t)-1 || off_write == (size_t)-1 || off_dc == (size_t)-1)
             return HJD_ERR_INTERNAL;
+        const size_t off_rst = maps.size(); // the sequential emulation's candidates
+        maps.insert(maps.end(), b->rst_images.begin(), b->rst_images.end());
         if (maps.size() & 1) maps.push_back(0); // the uint2 table that follows is 8-byte aligned
         off_group = maps.size();
         for (int k = 0; k < b->nimg; k++) {
@@ -686,6 +742,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->P.map_writewg = b->d_maps + off_write;
         b->P.map_dcchunk = b->d_maps + off_dc;
         b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
+        b->P.rst_list = b->d_maps + off_rst;
     }
     {   // stage everything that goes up in ONE pinned buffer: [scan bytes | image descriptors | tables | maps]
         const size_t o_img = align_up(raw_cur, 256), o_tab = align_up(o_img + sizeof(HjdImage) * b->nimg, 256);
@@ -699,14 +756,14 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             b->h_stage_cap = total + total / 16;
         }
         uint8_t *h = b->h_stage;
-        for (int i = 0; i < b->n; i++) {
+        parallel_for(b->n, raw_cur, [&](int i) {
             const int di = b->dev_index[i];
-            if (di < 0) continue;
+            if (di < 0) return;
             const HjdImage &im = b->img[di];
             memcpy(h + im.raw_off, parsed[i].stream, parsed[i].stream_len);
             const size_t slab = align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
             memset(h + im.raw_off + parsed[i].stream_len, 0, slab - parsed[i].stream_len); // the kernels read whole 16-byte pieces
-        }
+        });
         memcpy(h + o_img, b->img.data(), sizeof(HjdImage) * b->nimg);
         memcpy(h + o_tab, tabs.data(), sizeof(HjdTableSet) * tabs.size());
         memcpy(h + o_map, maps.data(), sizeof(uint32_t) * maps.size());
@@ -779,8 +836,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             r.group0 = a.group0;       r.ngroup = z.group0 + z.ngroups - a.group0;
             r.blk0 = (size_t)a.blk_off;
             r.nblk = (size_t)(z.blk_off + z.nblocks + 1 - a.blk_off);
+            for (size_t q = 0; q < b->rst_images.size(); q++)
+                if ((int)b->rst_images[q] >= i0 && (int)b->rst_images[q] < i1) {
+                    if (!r.nrst) r.rst0 = (uint32_t)q;
+                    r.nrst++;
+                }
             b->ranges.push_back(r);
             i0 = i1;
+        }
+        if (!b->rst_images.empty() && !b->seq_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&b->seq_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&b->seq_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b->seq_done, hipEventDisableTiming));
         }
         if (b->ranges.size() > 1) {
             while (b->istreams.size() < b->ranges.size()) {
@@ -920,7 +987,9 @@ extern "C" int hjd_batch_reset(hjd_batch *b, int n, const uint8_t *const *jpg, c
     std::vector<hjd_jpeg_data> parsed(n);
     std::vector<int> pst(n);
     const int pf = b->dec->conformant ? HJD_PARSE_CONFORMANT : 0;
-    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += jpg[i] ? jpg_len[i] : 0;
+    parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; });
     return batch_reset_parsed(b, n, parsed, pst, out_format, status, (hipStream_t)hip_stream, false);
 }
 
@@ -934,7 +1003,9 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
     std::vector<hjd_jpeg_data> parsed(n);
     std::vector<int> pst(n);
     const int pf = d->conformant ? HJD_PARSE_CONFORMANT : 0;
-    for (int i = 0; i < n; i++) pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += jpg[i] ? jpg_len[i] : 0;
+    parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; });
     return batch_from_parsed(d, n, parsed, pst, out_format, status);
 }
 
@@ -1004,6 +1075,27 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     return HJD_OK;
 }
 
+// After the run proper (everything of it is on `s` or joined to it): the sequential emulation of restart streams the parallel
+// path has just flagged DIRTY, then the back end once more for exactly those images — on the batch's side stream, which
+// waits for the run and which only hjd_batch_finish waits for.  Both launches are gated on the device: for a batch whose
+// restart streams are all clean they cost two launches of workgroups that return at once.
+static int emulation_enqueue(hjd_batch *b, hipStream_t s)
+{
+    if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_stream) return HJD_OK;
+    HIPCHK(hipEventRecord(b->seq_fork, s));
+    HIPCHK(hipStreamWaitEvent(b->seq_stream, b->seq_fork, 0));
+    if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream)) return HJD_ERR_INTERNAL;
+    for (uint32_t q : b->rst_images) { // the back end again for the candidates' groups; workgroups of clean images return at once
+        HjdParams P = b->P;
+        P.gate_emulated = 1u;
+        P.off_group = b->img[q].group0;
+        if (hjd_launch_idct_color(P, b->img[q].ngroups, b->seq_stream)) return HJD_ERR_INTERNAL;
+    }
+    HIPCHK(hipEventRecord(b->seq_done, b->seq_stream));
+    b->seq_pending = true;
+    return HJD_OK;
+}
+
 // Whole batch.  With one range (default) everything goes to the caller's stream; with several, each range
 // runs on an internal stream between a fork and a join event on the caller's stream.  Stage events
 // (names != nullptr) always use the single-stream form.
@@ -1015,6 +1107,9 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         if (nstage) *nstage = 0;
         return HJD_OK;
     }
+    // a run of this batch whose sequential emulation may still be at work on the side stream owns the batch's slabs until it
+    // is through (other batches are not held up)
+    if (b->seq_pending) HIPCHK(hipStreamWaitEvent(s, b->seq_done, 0));
     if (names || b->ranges.size() <= 1) {
         hjd_batch::Range all{};
         all.i0 = 0;
@@ -1026,7 +1121,9 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.ndc = b->ndcchunks;
         all.ngroup = b->ngroups;
         all.nblk = b->nblk_entries;
-        return range_enqueue(b, all, s, from_resync, nstage, names, evs);
+        all.nrst = (uint32_t)b->rst_images.size();
+        int rc = range_enqueue(b, all, s, from_resync, nstage, names, evs);
+        return rc ? rc : emulation_enqueue(b, s);
     }
     // range 0 stays on the caller's stream, the others fork off it: n ranges occupy n hardware queues, not n + 1 (a
     // process has four by default; a fifth stream shares one and serialises behind it).  Ranges are enqueued in order,
@@ -1044,7 +1141,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         if (k) HIPCHK(hipEventRecord(b->join_ev[k], sk));
     }
     for (size_t k = 1; k < b->ranges.size(); k++) HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
-    return HJD_OK;
+    return emulation_enqueue(b, s);
 }
 
 extern "C" int hjd_batch_run(hjd_batch *b, void *hip_stream)
@@ -1139,11 +1236,18 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     hipStream_t s = (hipStream_t)hip_stream;
     int overall = HJD_OK;
+    bool emulation_ran = false;
     if (b->nimg) {
         // normally one pass; if the induction check failed somewhere, run more synchronisation
         // launches (each propagates true states across one more workgroup boundary) and redo the output
         for (int attempt = 0;; attempt++) {
             HIPCHK(hipStreamSynchronize(s));
+            if (b->seq_pending) { // the sequential emulation of the restart streams this run flagged (enqueued by the run itself,
+                                  // on the side stream): its verdicts replace the parallel path's for those images
+                HIPCHK(hipEventSynchronize(b->seq_done));
+                b->seq_pending = false;
+                emulation_ran = true;
+            }
             HIPCHK(hipMemcpy(b->state.data(), b->d_st, sizeof(HjdImageState) * b->nimg, hipMemcpyDeviceToHost));
             bool stale = false;
             for (auto &st : b->state) stale |= (st.flags & HJD_FLAG_NOT_CONVERGED) != 0;
@@ -1154,7 +1258,10 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             }
             // everything from k_repair onwards runs again and raises its flags again (the ones a k_write pass
             // over stale states raised mean nothing); what k_unstuff_write found is not recomputed and must survive
-            for (auto &st : b->state) st.flags &= HJD_FLAG_BAD_MARKER;
+            for (auto &st : b->state) {
+                st.flags &= HJD_FLAG_BAD_MARKER;
+                st.emulated = 0;
+            }
             b->resyncs++;
             // keep ustream_len, nmarkers
             std::vector<HjdImageState> tmp = b->state;
@@ -1164,42 +1271,15 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             if (rc) return rc;
         }
     }
-    if (b->nimg && overall == HJD_OK && b->dec->dirty_mode == 0) {
-        // Restart streams on which the reference leaves the clean-resync domain (and nothing else is wrong): decode
-        // them again the way the reference does, one sequential lane per image (k_seq_decode), then the back end.
-        std::vector<uint32_t> dirty;
-        for (int k = 0; k < b->nimg; k++) {
-            const uint32_t f = b->state[k].flags;
-            if (f & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) dirty.push_back((uint32_t)k); // whatever else the parallel path flagged
-                                                                                          // after leaving the domain means nothing
-        }
-        if (!dirty.empty()) {
-            uint32_t *d_list = nullptr;
-            HIPCHK(hipMalloc(&d_list, sizeof(uint32_t) * dirty.size()));
-            int rc = HJD_OK;
-            if (hipMemcpyAsync(d_list, dirty.data(), sizeof(uint32_t) * dirty.size(), hipMemcpyHostToDevice, s) != hipSuccess) rc = HJD_ERR_INTERNAL;
-            if (rc == HJD_OK && hjd_launch_seq_decode(b->P, d_list, (uint32_t)dirty.size(), s)) rc = HJD_ERR_INTERNAL;
-            for (size_t q = 0; q < dirty.size() && rc == HJD_OK; q++) {
-                HjdParams P = b->P;
-                P.off_group = b->img[dirty[q]].group0;
-                if (hjd_launch_idct_color(P, b->img[dirty[q]].ngroups, s)) rc = HJD_ERR_INTERNAL;
-            }
-            if (rc == HJD_OK && hipStreamSynchronize(s) != hipSuccess) rc = HJD_ERR_INTERNAL;
-            if (rc == HJD_OK &&
-                hipMemcpy(b->state.data(), b->d_st, sizeof(HjdImageState) * b->nimg, hipMemcpyDeviceToHost) != hipSuccess)
-                rc = HJD_ERR_INTERNAL;
-            (void)hipFree(d_list);
-            if (rc != HJD_OK) return rc;
-            b->dirty_decodes += (int)dirty.size();
-        }
-    }
+    if (emulation_ran)
+        for (uint32_t q : b->rst_images) b->dirty_decodes += b->state[q].emulated ? 1 : 0;
     for (int i = 0; i < b->n; i++) {
         int st = b->parse_status[i];
         const int di = b->dev_index[i];
         if (st == HJD_OK && di >= 0) {
             const uint32_t f = b->state[di].flags;
             if (f & HJD_FLAG_NOT_CONVERGED) st = HJD_ERR_INTERNAL;
-            else if (f & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) st = HJD_ERR_DIRTY_RESTART;
+            else if (!b->state[di].emulated && (f & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER))) st = HJD_ERR_DIRTY_RESTART; // dirty_mode = 1
             else if (f & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN | HJD_FLAG_SHORT)) st = HJD_ERR_CORRUPT;
         }
         if (status) status[i] = st;
@@ -1450,12 +1530,18 @@ extern "C" int hjd_decode_batch_host(hjd_decoder *d, int n, const uint8_t *const
 
 // ---- single-image entry points (the reference's own API surface) -------------------------------
 
+// These calls are the reference's whole API (ConvertJpgFile, openjpg.cpp:593-684; JpegDecodeHW, loadjpg.h:180): one image per
+// call.  They share ONE decoder and ONE re-usable batch (hjd_batch_create + reset: the HBM slabs and the pinned staging
+// buffers stay allocated between calls — round 2 allocated and freed every slab per call), under one lock.
 static std::mutex g_mu;
 static hjd_decoder *g_dec = nullptr;
+static hjd_batch *g_batch = nullptr;
+static uint8_t *g_pin = nullptr; // pinned landing buffer for the output of the file-to-file call
+static size_t g_pin_cap = 0;
 
-static hjd_decoder *default_decoder()
+// g_mu held
+static hjd_decoder *default_decoder_locked()
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!g_dec) {
         int dev = 0;
         const char *e = getenv("HJD_DEVICE");
@@ -1465,31 +1551,48 @@ static hjd_decoder *default_decoder()
     return g_dec;
 }
 
-static int decode_one_parsed(const hjd_jpeg_data &j, int out_format, std::vector<uint8_t> &out)
+// Decodes one parsed image.  dst != nullptr: the output is copied there (dst_cap bytes at least); else it lands in the pinned
+// buffer and *pinned_out points at it (valid until the next call; the caller holds no lock then, so only hjd_convert_jpg_file,
+// which writes it out before returning under the lock, uses this form through `sink`).
+template <class Sink>
+static int decode_one_parsed(const hjd_jpeg_data &j, int out_format, uint8_t *dst, size_t dst_cap, Sink sink)
 {
-    hjd_decoder *d = default_decoder();
-    if (!d) return HJD_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lk(g_mu);
+    hjd_decoder *d = default_decoder_locked();
+    if (!d) return HJD_ERR_NO_DEVICE;
+    DeviceGuard guard(d->device);
+    if (!guard.ok) return HJD_ERR_NO_DEVICE;
+    if (!g_batch && !(g_batch = hjd_batch_create(d))) return HJD_ERR_INTERNAL;
     std::vector<hjd_jpeg_data> parsed(1, j);
     std::vector<int> pst(1, HJD_OK);
     int st = 0;
-    hjd_batch *b = batch_from_parsed(d, 1, parsed, pst, out_format, &st);
-    if (!b) return hjd_last_status();
-    int rc = st;
-    if (rc == HJD_OK) rc = hjd_batch_run(b, nullptr);
+    int rc = batch_reset_parsed(g_batch, 1, parsed, pst, out_format, &st, nullptr, false);
+    if (rc == HJD_OK) rc = st;
+    if (rc == HJD_OK) rc = hjd_batch_run(g_batch, nullptr);
     if (rc == HJD_OK) {
-        rc = hjd_batch_finish(b, nullptr, &st);
+        rc = hjd_batch_finish(g_batch, nullptr, &st);
         if (rc == HJD_OK) rc = st;
     }
-    if (rc == HJD_OK) {
-        size_t nb = 0;
-        hjd_batch_image_info(b, 0, nullptr, nullptr, nullptr, &nb);
-        out.resize(nb);
-        rc = hjd_batch_download(b, 0, out.data(), nb);
+    if (rc != HJD_OK) return rc;
+    size_t off = 0, nb = 0;
+    hjd_batch_image_info(g_batch, 0, nullptr, nullptr, &off, &nb);
+    if (dst) {
+        if (dst_cap < nb) return HJD_ERR_ARG;
+        HIPCHK(hipMemcpy(dst, g_batch->d_out + off, nb, hipMemcpyDeviceToHost));
+        return HJD_OK;
     }
-    hjd_batch_destroy(b);
-    return rc;
+    if (nb > g_pin_cap) {
+        if (g_pin) (void)hipHostFree(g_pin);
+        g_pin = nullptr;
+        g_pin_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&g_pin, nb + nb / 16, hipHostMallocDefault));
+        g_pin_cap = nb + nb / 16;
+    }
+    HIPCHK(hipMemcpy(g_pin, g_batch->d_out + off, nb, hipMemcpyDeviceToHost));
+    return sink(g_pin, nb);
 }
+
+static int no_sink(const uint8_t *, size_t) { return HJD_ERR_INTERNAL; }
 
 extern "C" int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int height, unsigned int width,
                                   unsigned char hFactor, unsigned char vFactor, unsigned char *rgb_out)
@@ -1510,9 +1613,7 @@ extern "C" int hjd_jpeg_decode_hw(const hjd_jpeg_data *jdata, unsigned int heigh
             return vst;
         }
     }
-    std::vector<uint8_t> out;
-    int rc = decode_one_parsed(j, HJD_OUT_RGB, out);
-    if (rc == HJD_OK) memcpy(rgb_out, out.data(), out.size());
+    const int rc = decode_one_parsed(j, HJD_OUT_RGB, rgb_out, hjd_rgb_bytes(width, height), no_sink);
     hjd_set_last_status(rc);
     return rc;
 }
@@ -1526,16 +1627,18 @@ extern "C" int hjd_decode_jpg_file_data(const unsigned char *buf, int sizeBuf, u
     }
     hjd_jpeg_data j;
     int rc = hjd_parse_header(buf, (size_t)sizeBuf, &j);
-    std::vector<uint8_t> out;
-    if (rc == HJD_OK) rc = decode_one_parsed(j, HJD_OUT_RGB, out);
+    unsigned char *pix = nullptr;
+    if (rc == HJD_OK) {
+        const size_t nb = hjd_rgb_bytes(j.width, j.height);
+        pix = (unsigned char *)malloc(nb ? nb : 1);
+        rc = pix ? decode_one_parsed(j, HJD_OUT_RGB, pix, nb, no_sink) : HJD_ERR_INTERNAL;
+    }
     hjd_set_last_status(rc);
-    if (rc != HJD_OK) return 0;
-    *rgbpix = (unsigned char *)malloc(out.size());
-    if (!*rgbpix) {
-        hjd_set_last_status(HJD_ERR_INTERNAL);
+    if (rc != HJD_OK) {
+        free(pix);
         return 0;
     }
-    memcpy(*rgbpix, out.data(), out.size());
+    *rgbpix = pix;
     *width = j.width;
     *height = j.height;
     return 1;
@@ -1555,9 +1658,8 @@ extern "C" int hjd_convert_jpg_file(const char *in, const char *outp)
     }
     hjd_jpeg_data j;
     int rc = hjd_parse_header(file.data(), file.size(), &j);
-    std::vector<uint8_t> bmp;
-    if (rc == HJD_OK) rc = decode_one_parsed(j, HJD_OUT_BMP, bmp);
-    if (rc == HJD_OK && !hjd_write_file(outp, bmp.data(), bmp.size())) rc = HJD_ERR_IO;
+    if (rc == HJD_OK) // the BMP file image lands in the pinned buffer and is written out from there (WriteBMP24, openjpg.cpp:504-570)
+        rc = decode_one_parsed(j, HJD_OUT_BMP, nullptr, 0, [&](const uint8_t *p, size_t nb) { return hjd_write_file(outp, p, nb) ? HJD_OK : HJD_ERR_IO; });
     hjd_set_last_status(rc);
     if (rc != HJD_OK) {
         fprintf(stderr, "hjd: %s: %s\n", in, hjd_status_string(rc));

@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C ABI, libhjd.so) against the CPU oracle and the golden
 hashes the compiled reference produced.  Bit-exact or fail."""
+import ctypes
 import hashlib
 import importlib
 import os
@@ -554,6 +555,53 @@ def test_bench_launches_its_own_ranks(tmp_path, world):
     assert line["n_gpus"] == world and line["config"]["images_per_gpu"] == 8 and line["parity"] == "ok"
     px = 8 * world * 1920 * 1080
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - px) / px < 0.02
+
+
+def test_two_host_threads_share_one_decoder(hjd, dec, golden):
+    """SURVEY §8b asks for a thread-safe ABI: two host threads drive ONE decoder, each with batches of its own on a stream
+    of its own (prepare / run / finish / download interleave freely; ctypes releases the GIL inside the calls), while a third
+    hammers the single-image entry point, which serialises on the library's one cached workspace.  Everything bit-exact."""
+    import threading
+    import torch
+    fx = _ok_fixtures(golden)
+    sets = [fx[0::2], fx[1::2]]
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            for rep in range(6):
+                mine = sets[k][rep % 3:] + sets[k][:rep % 3]
+                b = dec.prepare([f[2] for f in mine])
+                b.run(stream.cuda_stream)
+                st = b.finish(stream.cuda_stream)
+                for i, (name, ent, data) in enumerate(mine):
+                    if st[i] != 0 or hashlib.sha256(b.download(i).tobytes()).hexdigest() != ent["rgb_sha256"]:
+                        errors.append((k, rep, name, st[i]))
+                b.close()
+        except Exception as e:  # noqa
+            errors.append((k, repr(e)))
+
+    def single(k):
+        try:
+            name, ent, data = fx[k]
+            for rep in range(4):
+                rc, jd = hjd.parse_header(data)
+                out = np.empty(jd.width * jd.height * 3, np.uint8)
+                rc = hjd.lib().hjd_jpeg_decode_hw(ctypes.byref(jd), jd.height, jd.width, jd.hfactor, jd.vfactor, out.ctypes.data)
+                if rc != 0 or hashlib.sha256(out.tobytes()).hexdigest() != ent["rgb_sha256"]:
+                    errors.append(("single", name, rc))
+        except Exception as e:  # noqa
+            errors.append(("single", repr(e)))
+
+    th = [threading.Thread(target=worker, args=(0,)), threading.Thread(target=worker, args=(1,)),
+          threading.Thread(target=single, args=(0,)), threading.Thread(target=single, args=(3,))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+        assert not t.is_alive()
+    assert not errors, errors[:5]
 
 
 def test_empty_and_all_bad_batches(hjd, dec):
