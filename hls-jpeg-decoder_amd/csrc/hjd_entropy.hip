@@ -88,14 +88,16 @@ __device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp
 struct ReaderLds {
     uint32_t hi, lo, nxt, sh;
     const uint32_t *nx;
-    __device__ __forceinline__ void init(const uint32_t *rowp, uint32_t rel)
+    uint32_t stride; // words between successive words of the row in LDS: 64 in the staging windows of k_sync, rows + 1 in k_write
+    __device__ __forceinline__ void init(const uint32_t *rowp, uint32_t rel, uint32_t stride_words)
     {
+        stride = stride_words;
         const uint32_t k0 = rel >> 5, o0 = rel & 31u;
-        const uint32_t *sp = rowp + k0 * 64u;
-        const uint32_t a = sp[0], b = sp[64];
+        const uint32_t *sp = rowp + k0 * stride;
+        const uint32_t a = sp[0], b = sp[stride];
         hi = a;
         lo = o0 ? b : a;
-        nx = sp + (o0 ? 128 : 64);
+        nx = sp + (o0 ? 2u * stride : stride);
         sh = (32u - o0) & 31u;
         nxt = 0;
     }
@@ -107,7 +109,7 @@ struct ReaderLds {
         const bool roll = sh2 < 0;
         hi = roll ? lo : hi;
         lo = roll ? nxt : lo;
-        nx += roll ? 64 : 0;
+        nx += roll ? stride : 0u;
         sh = (uint32_t)sh2 & 31u;
     }
 };
@@ -172,7 +174,7 @@ __device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *_
                                           uint32_t end, uint32_t pair_lim, uint32_t &nblk, uint32_t &nrec, RestartCtx &rc)
 {
     ReaderLds rd;
-    rd.init(rowp, p - row_bit0);
+    rd.init(rowp, p - row_bit0, 64u);
     uint32_t mnext = 0xFFFFFFFFu;
     if (RESTART) {
         while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *_
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
                 if (p >= end) break;
-                rd.init(rowp, p - row_bit0);
+                rd.init(rowp, p - row_bit0, 64u);
             }
         } else if (RESTART) {
             if ((blk_end && p + 8u > mnext) || p > mnext) { // pulled back onto the next interval start
@@ -254,7 +256,7 @@ __device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *_
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
                 if (p >= end) break; // the next window is staged by the caller
-                rd.init(rowp, p - row_bit0);
+                rd.init(rowp, p - row_bit0, 64u);
             }
         }
     }
@@ -289,12 +291,12 @@ __device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *_
 // an end of block and at an AC coefficient in nearly every iteration, so every branch region is executed by every wave anyway
 // (round 2's loop: ~90 vector instructions per iteration, a third of them moves and mask juggling around the regions).
 template <bool RESTART>
-__device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+__device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t stride, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
     ReaderLds rd;
-    rd.init(rowp, p - row_bit0);
+    rd.init(rowp, p - row_bit0, stride);
     uint32_t mnext = 0xFFFFFFFFu;
     if (RESTART) {
         while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
@@ -389,7 +391,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
                 if (p >= end) break;
-                rd.init(rowp, p - row_bit0);
+                rd.init(rowp, p - row_bit0, stride);
             }
         } else if (RESTART) {
             if (blk_end) rc.left--;
@@ -410,7 +412,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 rc.mk++;
                 mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
                 if (p >= end) break; // the next window is staged by the caller
-                rd.init(rowp, p - row_bit0);
+                rd.init(rowp, p - row_bit0, stride);
             } else if (blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < W.nblocks) {
                 flags |= HJD_FLAG_DIRTY; // an interval ends here but the marker is not where the reference looks
                 rc.left = rc.ri_blocks;
@@ -420,12 +422,12 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
 }
 
 template <bool RESTART>
-__device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t row_bit0, uint32_t tabY,
+__device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t stride, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
     if (!RESTART) {
-        write_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        write_core<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
         return;
     }
     // see sync_span.  The plain loop keeps no count of the blocks left in the interval: it is brought up to date after it, and an
@@ -436,7 +438,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
         const uint32_t mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
         if (p + 40u <= mnext) {
             const uint32_t before = nblk;
-            write_core<false>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
+            write_core<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
             const uint32_t done = nblk - before;
             if (!rc.conf && rc.ri_blocks != 0u) {
                 if (done >= rc.left && before + rc.left < W.nblocks) {
@@ -448,7 +450,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
             }
             if (p >= end || nblk >= W.nblocks) break;
         }
-        write_core<true>(L, rowp, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        write_core<true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -503,37 +505,6 @@ __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, ui
             else sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
         }
         after_phase(ph);
-    }
-}
-
-// Final pass over ONE staging window (phase ph) of subsequence i (k_write).  left0 = blocks left in the restart interval
-// the lane's first block lies in.
-__device__ __forceinline__ void decode_window_write(const RowEnv &E, bool active, uint32_t i, uint32_t ph, uint32_t &p, uint32_t &z, uint32_t &m,
-                                                    uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, uint32_t left0)
-{
-    const HjdParams &P = *E.P;
-    const HjdImage &im = *E.im;
-    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
-    const uint32_t sp = i * S;
-    const uint32_t end = min(sp + S, E.total_bits);
-    const uint32_t bit0 = sp + ph * WPP * 32u;
-    const uint32_t pend = min(bit0 + WPP * 32u, end);
-    if (!(active && p < pend && nblk < W.nblocks)) return;
-    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, left0, im.conformant};
-    const uint32_t *src = row_base(E.wbase, i, lw) + (size_t)ph * WPP * 64u;
-    for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-    if (im.restart) {
-        rc.nmark = E.nmark;
-        uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rc.mpos[mid] <= p) lo = mid + 1;
-            else hi = mid;
-        }
-        rc.mk = lo;
-        write_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
-    } else {
-        write_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -926,13 +897,14 @@ __global__ __launch_bounds__(HJD_SYNC_WG) void k_repair_totals(HjdParams P) { sy
 
 // One lane per span of P.write_windows staging windows of a subsequence: k_sync's checkpoints hold the decoder state at every
 // window's end and the blocks / records decoded inside every window, so the final pass can start anywhere a window starts.
-// (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.
-// Short spans mean short chains but also lanes that wait for the longest of the 64 spans of their wave.)
+// (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.)
+// A workgroup covers G = HJD_WRITE_WG / (spans per subsequence) whole subsequences:
+// their words are loaded once, coalesced, into LDS ([word][row], rows + 1 apart), and every lane decodes its span from there.
 __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t bid = blockIdx.x + P.off_writewg;
     const int ii = (int)P.map_writewg[bid];
     const HjdImage &im = P.img[ii];
@@ -946,30 +918,41 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t *s_rows = s_w + 64;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
-    const uint32_t S = P.subseq_bits, nph = (S >> 5) / P.phase_words;
+    const uint32_t S = P.subseq_bits, wps = S >> 5, nph = wps / P.phase_words;
     const uint32_t WWN = P.write_windows, nu = nph / WWN; // windows per lane, lanes per subsequence
+    const uint32_t lnu = (uint32_t)__ffs((int)nu) - 1u;    // nu is a power of two
+    const uint32_t G = HJD_WRITE_WG >> lnu, stride = G + 1u; // subsequences of this workgroup; words between a row's words in LDS
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
     if (wg * HJD_WRITE_WG >= nsub * nu) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
+    {   // the workgroup's rows: word k of row i0 + r -> s_rows[k * stride + r] (rows past the scan's end stay unread)
+        const uint32_t i0 = wg * G, nrows = min(G, nsub - i0), lw = P.log2_words;
+        const uint32_t *wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
+        const uint32_t lg = (uint32_t)__ffs((int)G) - 1u; // G is a power of two
+        for (uint32_t idx = tid; idx < G * (wps + 2u); idx += HJD_WRITE_WG) {
+            const uint32_t k = idx >> lg, r = idx & (G - 1u);
+            if (r < nrows) s_rows[k * stride + r] = row_base(wbase, i0 + r, lw)[(size_t)k * 64u];
+        }
+    }
 
-    const uint32_t u = wg * HJD_WRITE_WG + tid; // lane span number
-    const uint32_t i = u / nu, ph = (u % nu) * WWN; // subsequence, first window
+    // lane tid <-> span u: subsequence u / nu, windows [(u % nu) * WWN, + WWN)
+    const uint2 *ckc = P.ckpt + (size_t)im.sub0 * nph; // [window][subsequence] of this image
+    const uint32_t u = wg * HJD_WRITE_WG + tid;
+    const uint32_t i = u >> lnu, ph = (u & (nu - 1u)) * WWN;
     const bool valid = i < nsub;
     const uint32_t g = im.sub0 + i;
-    const uint2 *ckc = P.ckpt + (size_t)im.sub0 * nph; // [window][subsequence] of this image
-    uint2 mine = make_uint2(0u, 0u); // x, y & 511: state at the end of the span; blocks and records inside it
+    uint2 mine = make_uint2(0u, 0u); // x, y & 511: state at the end of the span
     uint32_t my_blocks = 0, my_recs = 0;
     if (valid)
-        for (uint32_t w = 0; w < WWN; w++) {
-            mine = ckc[(size_t)(ph + w) * im.nsub_cap + i];
+        for (uint32_t q = 0; q < WWN; q++) {
+            mine = ckc[(size_t)(ph + q) * im.nsub_cap + i];
             my_blocks += (mine.y >> 9) & 2047u;
             my_recs += mine.y >> 20;
         }
-
-    // where this window's blocks and records go: totals of the workgroups before this one + scan inside
+    // where the spans' blocks and records go: totals of the workgroups before this one + scan inside
     uint32_t pb = 0, pr = 0;
     for (uint32_t k = tid; k < wg; k += HJD_WRITE_WG) {
         const uint2 t = P.wgsum[im.writewg0 + k];
@@ -986,18 +969,9 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         P.st[ii].total_blocks = base_b + tot_b;
         if (base_b + tot_b < im.nblocks) flags |= HJD_FLAG_SHORT;
     }
-
-    RowEnv E;
-    E.P = &P;
-    E.im = &im;
-    E.L = {s_lut, s_sec, s_mt};
-    E.tabY = table_pair(ts->slot_pack, 0, 2u);
-    E.tabCb = table_pair(ts->slot_pack, 1, 2u);
-    E.tabCr = table_pair(ts->slot_pack, 2, 2u);
-    E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
-    E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
-    E.total_bits = total_bits;
-    E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
+    __syncthreads(); // tables, rows and the prefix arrays are in LDS
+    // (Dealing the spans to the lanes in descending order of their length in steps — known from the checkpoints — was tried:
+    // 1 % fewer instructions.  Neighbouring spans are of like length already.)
 
     // start state: the checkpoint at the end of the window before; at a subsequence's first window the induction step
     // is checked — the subsequence's record must have been computed from its predecessor's end state
@@ -1025,15 +999,31 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
             m = zm >> 8;
         }
     }
-    __syncthreads(); // tables are in LDS
 
     WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
                   im.nblocks, s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
     W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
-    for (uint32_t w = 0; w < WWN; w++) {
-        const uint32_t left0 = im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u;
-        decode_window_write(E, go, i, ph + w, p, z, m, blk, nrec, W, flags, left0);
+    const uint32_t row_bit0 = i * S;
+    const uint32_t pend = min(row_bit0 + (ph + WWN) * P.phase_words * 32u, min(row_bit0 + S, total_bits));
+    if (go && p < pend && blk < im.nblocks) {
+        const EntropyLds L = {s_lut, s_sec, s_mt};
+        const uint32_t tabY = table_pair(ts->slot_pack, 0, 2u), tabCb = table_pair(ts->slot_pack, 1, 2u), tabCr = table_pair(ts->slot_pack, 2, 2u);
+        const uint32_t *rowp = s_rows + (i - wg * G);
+        RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u, im.conformant};
+        if (im.restart) {
+            rc.nmark = min(P.st[ii].nmarkers, im.mark_cap);
+            uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rc.mpos[mid] <= p) lo = mid + 1;
+                else hi = mid;
+            }
+            rc.mk = lo;
+            write_span<true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
+        } else {
+            write_span<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
+        }
     }
     // the span must end in the state, and with the record count, its checkpoints hold (else the places of everything
     // after it are wrong: the host re-synchronises) — unless the image was complete before the span's end
@@ -1052,7 +1042,9 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         if (nrec + HJD_REC_RUN - k <= im.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - k)) = make_uint4(W.r0, W.r1, W.r2, W.r3);
         else flags |= HJD_FLAG_OVERRUN;
     }
-    if (flags) atomicOr(&P.st[ii].flags, flags);
+    // one atomic per wave
+    for (int d = 32; d >= 1; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
+    if (lane == 0 && flags) atomicOr(&P.st[ii].flags, flags);
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------

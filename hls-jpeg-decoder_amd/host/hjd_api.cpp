@@ -524,6 +524,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     const uint32_t nph = (S / 32) / wpp; // windows per subsequence
     uint32_t wwn = d->write_windows;     // windows per k_write lane
     if (wwn > nph) wwn = nph;
+    while (wwn > 1 && (size_t)(S / 32 + 2) * (HJD_WRITE_WG / (nph / wwn) + 1) * 4 > (96u << 10)) wwn /= 2; // k_write keeps its rows in LDS
     const uint32_t nu = nph / wwn;       // k_write lanes per subsequence
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
@@ -674,7 +675,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_bytes_sync = (P.lds_state_word_s + 7 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
-        P.lds_bytes_write = (P.lds_state_word + 64 + (HJD_WRITE_WG / 64) * (wpp + 2) * 64) * 4;
+        // k_write: scan scratch, slot table, block table, then the workgroup's rows ([word][row], rows + 1 apart)
+        P.lds_bytes_write = (P.lds_state_word + 64 + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
 
