@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic: no hipEvents between the kernels of the timed steps")
+    ap.add_argument("--repeats", type=int, default=2, help="further timed regions of --steps steps after the reported one: their values are listed as `spread`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -293,6 +294,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # the same region again (not the reported value): how much one box varies from region to region
+    spread_dt = []
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        spread_dt.append(time.perf_counter() - t1)
+
     stages_all = []
     runs = 0
     for b, sh in zip(batches, streams):
@@ -348,6 +359,7 @@ def main():
         e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
 
     dt, total_pixels = shard.agree(dt, pixels, device="cuda" if backend == "nccl" else "cpu")  # MAX of time, SUM of pixels
+    spread_dt = [shard.agree(x, 0.0, device="cuda" if backend == "nccl" else "cpu")[0] for x in spread_dt]
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -465,6 +477,8 @@ def main():
             "stage_ms_isolated": {n: round(ms, 4) for n, ms in stages_iso},
             "stage_ms_overlapped": {n: round(ms, 4) for n, ms in stages_ovl},
             "timed_runs": runs,
+            "spread": {"further_regions_of_%d_steps" % args.steps: [round(total_pixels * args.steps / x / 1e6, 1) for x in spread_dt],
+                       "note": "same process, same batches, measured after the reported region; box to box the same build differs by a few per cent more"},
             "parity": parity,
             "parity_vs": sorted(parity_vs),
         }

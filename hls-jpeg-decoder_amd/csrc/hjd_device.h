@@ -52,16 +52,6 @@
 #define HJD_SEC_BITS (16 - HJD_LUT_BITS)
 #define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
 #define HJD_MAX_SEC 512
-// The same table in the canonical form the reference's matching rule is stated in ("is `code` one of the codes
-// of length k?", IsInHuffmanCodes, loadjpg.cpp:335-392) — for the sequential emulation kernel (hjd_seq.hip).
-struct HjdCanon {
-    uint16_t mincode[17]; // smallest code of each length
-    uint16_t count[17];   // codes of each length
-    uint16_t first[17];   // index into vals of the first code of each length
-    uint8_t vals[256];    // symbols in code order
-    uint8_t pad[2];
-};
-
 struct HjdTableSet {
     uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)
     uint32_t nsec;       // secondary tables in use
@@ -78,7 +68,6 @@ struct HjdTableSet {
     // starts inside the subsequence.  On the q85 bench content 38 % of the look-ups go away.
     uint16_t lut_s[HJD_SLOTS][HJD_LUT_SIZE][2];
     uint16_t sec_s[HJD_MAX_SEC][1 << HJD_SEC_BITS];
-    HjdCanon canon[HJD_SLOTS]; // per slot (component*2 + isAC)
 };
 
 struct HjdImage {
@@ -152,4 +141,5 @@ struct HjdImageState {
 // subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
 #define HJD_REC_ORPHAN (1u << 29) // the record's block began in an earlier k_write span: its slot is not in the block's mask
-#define HJD_REC_RUN 4 // records per aligned 16-byte store: every subsequence's run is padded to a multiple
+#define HJD_REC_RUN 8 // every k_write lane's run of records is padded to a multiple: a lane stores 32 aligned bytes at a time — a whole
+                      // sector (16-byte bursts, round 2, wrote every sector of the record array twice)

@@ -132,10 +132,11 @@ struct RestartCtx {
 };
 
 // WRITE: the lane's records waiting for their 16-byte store (shift register: r3 is the newest), and
-// where the outputs go.  Every subsequence's run of records starts at a multiple of HJD_REC_RUN, so
-// a full burst is one aligned global_store_dwordx4.
+// where the outputs go.  Every lane's run of records starts at a multiple of HJD_REC_RUN, so a full burst is
+// two aligned global_store_dwordx4 back to back: one 32-byte sector.
 struct WriteCtx {
-    uint32_t r0, r1, r2, r3;
+    uint32_t r0, r1, r2, r3; // the newest four records (shift register: r3 is the newest)
+    uint4 h;                 // the four before them, once a run's first half is complete
     uint32_t *rec;
     uint32_t rec_cap;
     uint4 *blk;
@@ -333,7 +334,9 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         W.bfirst = isdc ? nrec : W.bfirst;
         W.bdc = isdc ? (uint32_t)(int)(int16_t)val : W.bdc;
         W.tag = isdc ? (nblk & 127u) << 22 : W.tag;
+#if !defined(HJD_NO_DCD) // experiment switch: the DC kernels read the 16-byte entries instead
         if (isdc) W.dcd[nblk] = (int16_t)val;
+#endif
         // the reference looks for a marker again between the DC code and its extra bits
         if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
         const uint32_t zw = z + adv - 1u;
@@ -347,9 +350,20 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             W.r1 = W.r2;
             W.r2 = W.r3;
             W.r3 = w;
-            const bool burst = (nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u;
-            flags |= (burst && nrec >= W.rec_cap) ? HJD_FLAG_OVERRUN : 0u;
-            if (burst && nrec < W.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - (HJD_REC_RUN - 1u))) = make_uint4(W.r0, W.r1, W.r2, W.r3);
+            static_assert(HJD_REC_RUN == 8, "two 16-byte halves per burst");
+            if ((nrec & 3u) == 3u) { // four more records complete
+                if (nrec & 4u) { // ... and with them a burst of eight: one 32-byte sector
+                    if (nrec < W.rec_cap) {
+                        uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - 7u));
+                        dst[0] = W.h;
+                        dst[1] = make_uint4(W.r0, W.r1, W.r2, W.r3);
+                    } else {
+                        flags |= HJD_FLAG_OVERRUN;
+                    }
+                } else {
+                    W.h = make_uint4(W.r0, W.r1, W.r2, W.r3);
+                }
+            }
             nrec++;
         }
         z += adv;
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         }
     }
 
-    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
+    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, make_uint4(HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD), P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
                   im.nblocks, s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
     W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
@@ -1033,14 +1047,21 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the span ends inside a block it owns
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
-        for (uint32_t q = k; q < HJD_REC_RUN; q++) {
+        for (uint32_t q = k & 3u; q != 0u && q < 4u; q++) { // bring the newest 1..3 records to the front of their half
             W.r0 = W.r1;
             W.r1 = W.r2;
             W.r2 = W.r3;
             W.r3 = HJD_REC_PAD;
         }
-        if (nrec + HJD_REC_RUN - k <= im.rec_cap) *reinterpret_cast<uint4 *>(W.rec + (nrec - k)) = make_uint4(W.r0, W.r1, W.r2, W.r3);
-        else flags |= HJD_FLAG_OVERRUN;
+        const uint4 pad = make_uint4(HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD), r = make_uint4(W.r0, W.r1, W.r2, W.r3);
+        const uint4 first = k < 4u ? r : W.h, second = k <= 4u ? pad : r;
+        if (nrec + HJD_REC_RUN - k <= im.rec_cap) {
+            uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - k));
+            dst[0] = first;
+            dst[1] = second;
+        } else {
+            flags |= HJD_FLAG_OVERRUN;
+        }
     }
     // one atomic per wave
     for (int d = 32; d >= 1; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);

@@ -298,13 +298,13 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     // (short)(int) cast.
     {
         const uint32_t *rec = P.rec + im.rec_off;
-        // A group holds at most 63 records per block, and every subsequence's run with k >= 1 of them inside the group
-        // is padded to at most k + 3 <= 4k entries: 4 * 63 * KB bounds the span of any real group (round 2 capped it at
-        // MAXGB * 64 + 1024, which dense q100 content exceeds at 64-bit subsequences: records dropped without a
-        // status).  Entries left over from a run that failed half-way (the image then carries an error status) still
-        // cannot turn this loop into a walk over the whole record array.
+        // A group holds at most 63 records per block, and every k_write lane's run with k >= 1 of them inside the group
+        // is padded to at most k + HJD_REC_RUN - 1 <= HJD_REC_RUN * k entries: that bounds the span of any real group
+        // (round 2 capped it at MAXGB * 64 + 1024, which dense q100 content exceeds at 64-bit subsequences: records
+        // dropped without a status).  Entries left over from a run that failed half-way (the image then carries an error
+        // status) still cannot turn this loop into a walk over the whole record array.
         const uint32_t r0 = s_range[0];
-        const uint32_t r1 = min(s_range[1], r0 + 4u * 63u * KB + 4u);
+        const uint32_t r1 = min(s_range[1], r0 + HJD_REC_RUN * 63u * KB + HJD_REC_RUN);
         const uint32_t b0 = (uint32_t)(gm.y - im.blk_off);
         for (uint32_t t = (r0 & ~3u) + tid * 4u; t < r1; t += 1024u) {
             const uint4 q = *reinterpret_cast<const uint4 *>(rec + t);

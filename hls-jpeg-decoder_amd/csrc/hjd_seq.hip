@@ -88,15 +88,6 @@ struct SeqReader { // stHuffmanData::m_stream / stream_index / g_reservoir / g_n
     }
 };
 
-// IsInHuffmanCodes (loadjpg.cpp:335-392): is `code` a code of length k?  Canonical form of the table.
-__device__ __forceinline__ bool seq_match(const HjdCanon &t, uint32_t code, uint32_t k, uint32_t &value)
-{
-    const uint32_t c = t.count[k];
-    if (c == 0u || code < t.mincode[k] || code >= t.mincode[k] + c) return false;
-    value = t.vals[t.first[k] + (code - t.mincode[k])];
-    return true;
-}
-
 __device__ __forceinline__ int seq_extend(uint32_t v, uint32_t n) // DetermineSign, loadjpg.cpp:396-409
 {
     return v < (1u << (n - 1u)) ? (int)v - (int)((1u << n) - 1u) : (int)v;
@@ -106,19 +97,40 @@ __device__ __forceinline__ int seq_extend(uint32_t v, uint32_t n) // DetermineSi
 // every run of a batch that holds such images, on a side stream: no host round trip, no allocation — hjd_api.cpp).
 __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
 {
-    __shared__ HjdCanon s_canon[HJD_SLOTS]; // the code tables, out of LDS: the matching loop reads them three times per code length
+    // The reference tries the code lengths one after the other (IsInHuffmanCodes over k = 1..16, loadjpg.cpp:562, :713); for the
+    // prefix-free tables the parser admits that finds the same (length, symbol) as one look-up of the next 16 bits in the
+    // decode tables of the parallel path, and the k FillNBits calls of the search leave the reader where one FillNBits(length)
+    // leaves it (each loads at most the one byte that is missing).  So: peek 16 bits on a COPY of the reader, look the code up
+    // (11-bit primary table in LDS, secondary in HBM), then consume it with the reader proper.  (Length by length out of LDS
+    // this kernel spent 0.9 us per symbol; it is a one-lane chain, so that is its speed.)
+    __shared__ uint16_t s_lut[HJD_SLOTS][HJD_LUT_SIZE];
     const int ii = (int)P.rst_list[first + blockIdx.x];
     if (!(P.st[ii].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER))) return; // whatever else the parallel path flagged after leaving
                                                                             // the clean-resync domain means nothing
     const HjdImage &im = P.img[ii];
+    const HjdTableSet &ts = P.tabs[im.tabset];
     {
-        static_assert(sizeof(HjdCanon) % 4 == 0, "copied by words");
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&P.tabs[im.tabset].canon[0]);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&s_canon[0]);
-        for (uint32_t k = threadIdx.x; k < sizeof(s_canon) / 4u; k += 64u) dst[k] = src[k];
+        const uint4 *src = reinterpret_cast<const uint4 *>(&ts.lut[0][0]);
+        uint4 *dst = reinterpret_cast<uint4 *>(&s_lut[0][0]);
+        for (uint32_t k = threadIdx.x; k < ts.nlut * (HJD_LUT_SIZE * 2u / 16u); k += 64u) dst[k] = src[k];
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    // (length, value bits, zig-zag advance) of the code at the head of the reader's bits, table `ti`; false = no such code
+    auto peek_code = [&](const SeqReader &r0, uint32_t ti, uint32_t &len, uint32_t &size, uint32_t &adv) -> bool {
+        SeqReader t = r0;
+        t.fill(16u); // at most two bytes: 16 bits are there afterwards
+        const uint32_t c16 = (t.res >> (t.nbits - 16u)) & 0xFFFFu;
+        uint32_t e = s_lut[ti][c16 >> (16 - HJD_LUT_BITS)];
+        if ((e & 31u) == 0u) {
+            const uint32_t sub = e >> 5;
+            e = sub ? ts.sec[sub - 1u][c16 & (HJD_SEC_SIZE - 1u)] : 0u;
+        }
+        len = e & 31u;
+        size = (e >> 5) & 15u;
+        adv = e >> 9;
+        return len != 0u;
+    };
     SeqReader r;
     r.s = P.raw + im.raw_off;
     r.n = im.scan_len;
@@ -133,67 +145,59 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
     for (uint32_t b = 0; b < im.nblocks && !flags; b++) {
         const uint32_t m = b % im.nb;
         const uint32_t comp = m < im.nby ? 0u : m - im.nby + 1u; // DecodeMCU order, :945-997
-        const HjdCanon &hdc = s_canon[comp * 2], &hac = s_canon[comp * 2 + 1];
+        const uint32_t tdc = (ts.slot_pack >> (comp * 8u)) & 7u, tac = (ts.slot_pack >> (comp * 8u + 4u)) & 7u;
         const uint32_t first = nrec;
-        uint32_t mlo = 0, mhi = 0, sym = 0;
+        uint32_t mlo = 0, mhi = 0;
 
         if (restart && r.on_marker()) r.resync(); // block-start check, :535-550
 
-        bool found = false;
         int dc = prev[comp];
-        for (uint32_t k = 1; k < 16; k++) { // :562: DC codes of 1..15 bits
-            r.fill(k);
-            if (seq_match(hdc, r.res >> (r.nbits - k), k, sym)) {
-                r.skip(k);
-                found = true;
-                if (sym != 0u) {
-                    if (restart && r.on_marker()) r.resync(); // between the code and its extra bits, :631-640
-                    const int data = (int)(int16_t)seq_extend(r.get(sym), sym);
-                    dc = (int)(int16_t)(data + prev[comp]); // :664
-                    prev[comp] = dc;
-                }
+        {
+            uint32_t len, size, adv;
+            // :562: DC codes of 1..15 bits.  No match: the reference prints and carries on with the AC loop on the same bits
+            // (:680-685): not emulated
+            if (!peek_code(r, tdc, len, size, adv) || len > 15u) {
+                flags |= HJD_FLAG_BAD_CODE;
                 break;
             }
-        }
-        if (!found) { // the reference prints and carries on with the AC loop on the same bits (:680-685): not emulated
-            flags |= HJD_FLAG_BAD_CODE;
-            break;
+            r.skip(len);
+            if (size != 0u) {
+                if (restart && r.on_marker()) r.resync(); // between the code and its extra bits, :631-640
+                const int data = (int)(int16_t)seq_extend(r.get(size), size);
+                dc = (int)(int16_t)(data + prev[comp]); // :664
+                prev[comp] = dc;
+            }
         }
 
         uint32_t nr = 1;
         bool eob = false;
         while (nr <= 63u && !eob) { // :700
-            bool hit = false;
-            for (uint32_t k = 1; k <= 16; k++) { // :713
-                r.fill(k);
-                if (seq_match(hac, r.res >> (r.nbits - k), k, sym)) {
-                    r.skip(k);
-                    hit = true;
-                    const uint32_t size = sym & 15u, run = sym >> 4; // :768-769
-                    if (size == 0u) {
-                        if (run == 0u) eob = true;      // :773
-                        else if (run == 15u) nr += 16u; // :774; other runs with size 0 are ignored
-                        else if (r.idx > im.scan_len + 4u) flags |= HJD_FLAG_BAD_CODE; // an ignored symbol decoded from the zeros
-                                                                                      // past the end: the reference repeats it forever
-                    } else {
-                        nr += run; // :778
-                        if (nr > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806)
-                            flags |= HJD_FLAG_OVERRUN;
-                            break;
-                        }
-                        const int data = (int)(int16_t)seq_extend(r.get(size), size);
-                        const uint32_t slot = c_zz_to_slot_seq[nr];
-                        if (nrec < im.rec_cap) rec[nrec] = ((uint32_t)data & 0xFFFFu) | (slot << 16) | ((b & 127u) << 22);
-                        else flags |= HJD_FLAG_OVERRUN;
-                        nrec++;
-                        nr++;
-                        if (slot < 32u) mlo |= 1u << slot;
-                        else mhi |= 1u << (slot - 32u);
-                    }
+            uint32_t len, size, adv;
+            if (!peek_code(r, tac, len, size, adv)) { // no code of 1..16 bits: the reference's loop makes no progress
+                flags |= HJD_FLAG_BAD_CODE;
+                break;
+            }
+            r.skip(len);
+            if (size == 0u) { // :768-775: adv = 64 end of block, 16 ZRL, 0 any other run with size 0 (ignored)
+                if (adv == 64u) eob = true;
+                else if (adv == 16u) nr += 16u;
+                else if (r.idx > im.scan_len + 4u) flags |= HJD_FLAG_BAD_CODE; // an ignored symbol decoded from the zeros past
+                                                                               // the end: the reference repeats it forever
+            } else {
+                nr += adv - 1u; // run, :778
+                if (nr > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806)
+                    flags |= HJD_FLAG_OVERRUN;
                     break;
                 }
+                const int data = (int)(int16_t)seq_extend(r.get(size), size);
+                const uint32_t slot = c_zz_to_slot_seq[nr];
+                if (nrec < im.rec_cap) rec[nrec] = ((uint32_t)data & 0xFFFFu) | (slot << 16) | ((b & 127u) << 22);
+                else flags |= HJD_FLAG_OVERRUN;
+                nrec++;
+                nr++;
+                if (slot < 32u) mlo |= 1u << slot;
+                else mhi |= 1u << (slot - 32u);
             }
-            if (!hit) flags |= HJD_FLAG_BAD_CODE; // no code of 1..16 bits: the reference's loop makes no progress
             if (flags) break;
         }
         blk[b] = make_uint4(first, 0u, mlo, mhi);

@@ -284,18 +284,6 @@ static bool build_tabset(HjdTableSet &ts, const hjd_jpeg_data &j)
         specs[(c - 1) * 2 + 0] = &j.htdc[j.dc_table_index[c]];
         specs[(c - 1) * 2 + 1] = &j.htac[j.ac_table_index[c]];
     }
-    for (int sl = 0; sl < HJD_SLOTS; sl++) { // canonical form for the sequential emulation kernel (GenHuffCodes, openjpg.cpp:48-66)
-        HjdCanon &c = ts.canon[sl];
-        unsigned code = 0, idx = 0;
-        for (int k = 1; k <= 16; k++) {
-            c.mincode[k] = (uint16_t)code;
-            c.count[k] = specs[sl]->bits[k];
-            c.first[k] = (uint16_t)idx;
-            code = (code + specs[sl]->bits[k]) << 1;
-            idx += specs[sl]->bits[k];
-        }
-        memcpy(c.vals, specs[sl]->vals, 256);
-    }
     for (int sl = 0; sl < HJD_SLOTS; sl++) {
         int ti = -1;
         for (int q = 0; q < sl; q++)
@@ -1087,11 +1075,13 @@ static int emulation_enqueue(hjd_batch *b, hipStream_t s)
     HIPCHK(hipEventRecord(b->seq_fork, s));
     HIPCHK(hipStreamWaitEvent(b->seq_stream, b->seq_fork, 0));
     if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream)) return HJD_ERR_INTERNAL;
-    for (uint32_t q : b->rst_images) { // the back end again for the candidates' groups; workgroups of clean images return at once
+    {   // the back end again, ONE launch over the groups from the first to the last candidate: the workgroups of every image the
+        // emulation has not touched return at once
         HjdParams P = b->P;
         P.gate_emulated = 1u;
-        P.off_group = b->img[q].group0;
-        if (hjd_launch_idct_color(P, b->img[q].ngroups, b->seq_stream)) return HJD_ERR_INTERNAL;
+        const HjdImage &a = b->img[b->rst_images.front()], &z = b->img[b->rst_images.back()];
+        P.off_group = a.group0;
+        if (hjd_launch_idct_color(P, z.group0 + z.ngroups - a.group0, b->seq_stream)) return HJD_ERR_INTERNAL;
     }
     HIPCHK(hipEventRecord(b->seq_done, b->seq_stream));
     b->seq_pending = true;

@@ -9,7 +9,7 @@ hjd = importlib.import_module("hls-jpeg-decoder_amd")
 src = [T.synth_jpeg(3840, 2160, 1000 + s, 85, 2, 2) for s in range(4)]
 for n in (1, 2, 4, 8, 16):
     jpgs = [src[i % 4] for i in range(n)]
-    for S in (0, 256, 512, 1024, 2048):
+    for S in (0, 512, 1024, 2048, 4096):
         d = hjd.Decoder(0, subseq_bits=S)
         b = d.prepare(jpgs)
         for _ in range(3):
