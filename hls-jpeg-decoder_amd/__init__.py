@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_parse_header_ex", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query", "hjd_debug_sync_profile",
 ]
 
 

@@ -113,7 +113,8 @@ typedef enum hjd_out_format {
 
 typedef struct hjd_options {
     int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..16384); 0 = chosen per batch from its scan bytes */
-    int sync_launches;   /* synchronisation + repair launches before verification; 0 = default */
+    int sync_launches;   /* 1 + in-stream repair launches after the synchronisation launch; 0 = default (1: the final pass checks
+                          * every start state and hjd_batch_finish repairs from the host if one is ever stale) */
     int streams;         /* image ranges a batch is split into, each on its own HIP stream (the first on the caller's; the
                           * others forked from and joined to it): one range's latency-bound synchronisation then overlaps
                           * another's IDCT.  0 = by batch size (1 below 60 Mpixel, 2 up to 400, 3 above), 1 = no split */
@@ -175,11 +176,16 @@ int hjd_batch_collect_timing(hjd_batch *b, float *stage_ms_avg, const char **sta
  * synchronisation workgroups, subsequence decodes executed while synchronising, max iterations of one
  * workgroup, number of subsequences}. */
 int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
+/* Diagnostics, only with HJD_SYNC_PROF=1 in the environment when the batch was laid out: shader-clock stamps of the stages of
+ * every synchronisation workgroup of the last run (32 words per workgroup: clock, tag pairs; tools/sync_profile.py).  Returns the
+ * number of workgroups, or -1. */
+int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, size_t cap_words);
 /* Number of host-driven re-synchronisation rounds hjd_batch_finish had to run since prepare
- * (0 in normal operation: the in-stream repair launch already settled every state). */
+ * (0 in normal operation: the warm-up subsequences of every synchronisation workgroup settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);
-/* Number of images of this batch that hjd_batch_finish decoded with the sequential emulation of the reference
- * (restart streams outside the clean-resync domain) since prepare / reset. */
+/* Number of images of this batch that went through the sequential emulation of the reference (restart streams outside the
+ * clean-resync domain) in the runs finished since prepare / reset.  The emulation is enqueued by hjd_batch_run itself, on a
+ * side stream: statuses and outputs of such images are final after hjd_batch_finish. */
 int hjd_batch_sequential_count(const hjd_batch *b);
 
 /* A batch object that can be prepared again and again in place: slabs and pinned staging are re-allocated only
