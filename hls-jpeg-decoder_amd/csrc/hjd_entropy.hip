@@ -341,11 +341,15 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
         const uint32_t zw = z + adv - 1u;
         if (!isdc && s != 0u) { // AC run/size: loadjpg.cpp:776-808
-            const bool over = zw > 63u;
             const uint32_t slot = W.slot_of[zw & 63u];
-            const uint32_t w = over ? HJD_REC_PAD : (((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag);
-            flags |= over ? HJD_FLAG_OVERRUN : 0u;
-            W.mask |= over ? 0ull : 1ull << slot;
+            uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag;
+            if (zw > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806): flagged, never a record (a rare branch:
+                            // no lane of a wave takes it on a stream the reference can decode)
+                flags |= HJD_FLAG_OVERRUN;
+                w = HJD_REC_PAD;
+            } else {
+                W.mask |= 1ull << slot;
+            }
             W.r0 = W.r1;
             W.r1 = W.r2;
             W.r2 = W.r3;

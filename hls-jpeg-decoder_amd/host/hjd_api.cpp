@@ -429,6 +429,7 @@ static int slab_reserve(hjd_batch *b, T *&p, size_t bytes)
 
 static void batch_free_device(hjd_batch *b)
 {
+    if (b->seq_stream) (void)hipStreamSynchronize(b->seq_stream); // a sequential emulation of the last run may still be at work on the slabs
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     (void)hipFree(b->d_img);
     (void)hipFree(b->d_st);
@@ -491,6 +492,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->dirty_decodes = 0;
     DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
+    if (b->seq_pending) { // the previous contents' sequential emulation (side stream) still owns the slabs
+        HIPCHK(hipEventSynchronize(b->seq_done));
+        b->seq_pending = false;
+    }
     // Subsequence size: every lane of k_sync decodes one subsequence serially (k_write runs one lane per staging window whatever
     // the subsequence size), so a small batch wants short ones and a large batch long ones (fewer synchronisation
     // workgroups, tables loaded less often: 64 x 4K on four streams, 240 Gpixel/s at 2048 bits, 270 at 4096).  Unless the
