@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: everything that goes under profiles/ (run on the GPU box through gpurun)
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; cd $R
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; cd $R   # NB: remove the build container's gpurun_out/r03_* before merging a new run (tools/collect_round.sh averages what it finds)
 python3 bench.py > $O/r03_bench.json 2> $O/r03_bench.err; tail -c 400 $O/r03_bench.json
 bash tools/gpu_profile.sh r03 all
 cd $R
