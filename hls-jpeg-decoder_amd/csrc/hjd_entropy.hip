@@ -157,7 +157,10 @@ struct WriteCtx {
 // records in the back end.)
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
-    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint4(W.bfirst, W.bdc, (uint32_t)W.mask, (uint32_t)(W.mask >> 32));
+    if (W.bfirst != 0xFFFFFFFFu) {
+        W.blk[b] = make_uint4(W.bfirst, W.bdc, (uint32_t)W.mask, (uint32_t)(W.mask >> 32));
+        W.dcd[b] = (int16_t)W.bdc; // the DC difference once more, compact, for the DC prediction kernels
+    }
     W.bfirst = 0xFFFFFFFFu;
     W.mask = 0ull;
 }
@@ -334,9 +337,6 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         W.bfirst = isdc ? nrec : W.bfirst;
         W.bdc = isdc ? (uint32_t)(int)(int16_t)val : W.bdc;
         W.tag = isdc ? (nblk & 127u) << 22 : W.tag;
-#if !defined(HJD_NO_DCD) // experiment switch: the DC kernels read the 16-byte entries instead
-        if (isdc) W.dcd[nblk] = (int16_t)val;
-#endif
         // the reference looks for a marker again between the DC code and its extra bits
         if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
         const uint32_t zw = z + adv - 1u;

@@ -166,10 +166,12 @@ __device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__re
             }
             const uint32_t row0 = cy << lvf;
             uint8_t *dst = dst0 + (ptrdiff_t)row0 * rstep;
-            for (uint32_t dy = 0; dy < vf; dy++, dst += rstep) {
+            // the vf luma rows of one chroma row lie in the same tile row (vf divides 8): one address, stepped by a tile line
+            const uint8_t *yp = ytile + (row0 >> 3) * (HF * (uint32_t)sizeof(s_pix[0])) + (row0 & 7u) * 8u;
+            for (uint32_t dy = 0; dy < vf; dy++, dst += rstep, yp += 8) {
                 const uint32_t row = row0 + dy;
                 if (gy0 + row >= H) break; // loadjpg.cpp:908
-                const uint32_t ypix = *reinterpret_cast<const uint32_t *>(ytile + (row >> 3) * (HF * (uint32_t)sizeof(s_pix[0])) + (row & 7u) * 8u);
+                const uint32_t ypix = *reinterpret_cast<const uint32_t *>(yp);
                 uint32_t d0, d1, d2;
                 rgb12<BMP, CONF>(ypix, t0, t1, t2, t3, d0, d1, d2);
                 if (wide || (nvalid == 4u && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0u)) {

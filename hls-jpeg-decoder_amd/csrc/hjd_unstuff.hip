@@ -258,22 +258,15 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
 
 #define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
 
-__device__ __forceinline__ void dc_thread_sums(const int16_t *d, const uint4 *blk4, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+__device__ __forceinline__ void dc_thread_sums(const int16_t *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
                                                uint32_t &y, uint32_t &cb, uint32_t &cr)
 {
     y = cb = cr = 0;
     for (uint32_t mc = m0; mc < m1; mc++) {
-#if defined(HJD_NO_DCD)
-        const uint4 *q4 = blk4 + (size_t)mc * nb;
-        for (uint32_t k = 0; k < nby; k++) y += q4[k].y;
-        cb += q4[nby].y;
-        cr += q4[nby + 1].y;
-#else
         const int16_t *q = d + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) y += (uint32_t)(int)q[k];
         cb += (uint32_t)(int)q[nby];
         cr += (uint32_t)(int)q[nby + 1];
-#endif
     }
 }
 
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
     const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     uint32_t y, cb, cr, ty, tcb, tcr;
-    dc_thread_sums(P.dcd + im.blk_off, P.blk + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
+    dc_thread_sums(P.dcd + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
     block_excl_scan(y, s_w, &ty);
     block_excl_scan(cb, s_w, &tcb);
     block_excl_scan(cr, s_w, &tcr);
@@ -322,18 +315,12 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     const int16_t *d = P.dcd + im.blk_off;
     int16_t *o = P.dca + im.blk_off;
     uint32_t y, cb, cr;
-    dc_thread_sums(d, P.blk + im.blk_off, m0, m1, nb, nby, y, cb, cr);
+    dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
     y = by + block_excl_scan(y, s_w, &t);
     cb = bcb + block_excl_scan(cb, s_w, &t);
     cr = bcr + block_excl_scan(cr, s_w, &t);
     for (uint32_t mc = m0; mc < m1; mc++) {
-#if defined(HJD_NO_DCD)
-        const uint4 *q4 = P.blk + im.blk_off + (size_t)mc * nb;
-        int16_t q[8];
-        for (uint32_t k = 0; k < nb; k++) q[k] = (int16_t)q4[k].y;
-#else
         const int16_t *q = d + (size_t)mc * nb;
-#endif
         int16_t *w = o + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) {
             y += (uint32_t)(int)q[k];
