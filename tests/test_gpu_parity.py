@@ -204,6 +204,35 @@ def test_dense_records_at_small_subsequences(hjd, bits):
     d.close()
 
 
+@pytest.mark.parametrize("env", [{"HJD_PHASE_WORDS": "2"}, {"HJD_PHASE_WORDS": "4", "HJD_WRITE_WINDOWS": "2"}, {"HJD_PHASE_WORDS": "8", "HJD_WRITE_WINDOWS": "8"},
+                                 {"HJD_PHASE_WORDS": "32"}, {"HJD_LANE_WARM": "3"}, {"HJD_SYNC_CONC": "0", "HJD_STAGGER": "1"},
+                                 {"HJD_SYNC_OVERLAP": "0"}, {"HJD_SYNC_OVERLAP": "1"}])
+def test_tuning_knobs_never_change_a_byte(hjd, golden, env):
+    """Window size (= checkpoint spacing = what one k_write lane decodes), windows per k_write lane, warm-up inside the lanes of
+    k_sync's round 0, the front-end concurrency limit, staggered ranges, in-stream repair launches, none or a single warm-up
+    subsequence per synchronisation workgroup: tuning only.  The knobs are read when a decoder is created."""
+    fx = _ok_fixtures(golden, restart=("none", "clean", "dirty"))
+    big = [T.synth_jpeg(1280, 720, 4242, 85, 2, 2), T.synth_jpeg(1000, 700, 4243, 90, 1, 1, 25, 9.0)]
+    want = [T.oracle_decode(j)[1] for j in big]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for bits, streams, launches in ((0, 0, 0), (512, 3, 3), (4096, 2, 2)):
+            d = hjd.Decoder(0, subseq_bits=bits, streams=streams, sync_launches=launches)
+            st, outs = d.decode([f[2] for f in fx] + big)
+            for (name, ent, data), s, o in zip(fx, st, outs):
+                assert s == 0 and hashlib.sha256(o.tobytes()).hexdigest() == ent["rgb_sha256"], (name, env, bits)
+            for o, w in zip(outs[len(fx):], want):
+                assert np.array_equal(o, w), (env, bits)
+            d.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_restart_fixtures(hjd, dec, golden):
     """Committed restart-marker fixtures: the output equals the compiled reference's — inside the clean-resync
     domain through the parallel path, and for the dirty one (the reference fires its resync early on tiny blocks,
