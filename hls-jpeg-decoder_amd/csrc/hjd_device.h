@@ -34,9 +34,7 @@
 #define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
 #endif
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
-#ifndef HJD_GROUP_MCUS
-#define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup (8 or 16)
-#endif
+#define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 
 // Huffman decode tables of one distinct (DC/AC x 3 components) configuration.

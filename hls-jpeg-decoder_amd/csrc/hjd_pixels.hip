@@ -129,8 +129,7 @@ __device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__re
     const uint32_t W = im.width, H = im.height, vf = im.vf, nb = im.nb, nby = im.nby;
     const uint32_t stride = im.out_stride;
     constexpr uint32_t LHF = HF >> 1;      // log2 for 1, 2, 4
-    static_assert(HJD_GROUP_MCUS == 16 || HJD_GROUP_MCUS == 8, "the unit grid is a bit field of the thread index");
-    constexpr uint32_t LUPR = (HJD_GROUP_MCUS == 16 ? 5u : 4u) + LHF; // log2(4-pixel units per padded row) = log2(HJD_GROUP_MCUS * 2 * HF)
+    constexpr uint32_t LUPR = 5u + LHF;    // log2(4-pixel units per padded row) = log2(HJD_GROUP_MCUS * 2 * HF)
     constexpr uint32_t MW = 8u * HF;
     const uint32_t mh = 8u * vf, lvf = vf >> 1;
     // The unit grid is padded to HJD_GROUP_MCUS MCUs per row so that a unit's row and column are bit fields of the thread index.
