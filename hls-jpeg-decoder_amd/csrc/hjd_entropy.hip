@@ -131,12 +131,12 @@ struct RestartCtx {
     uint32_t conf;        // conformant mode (hjd_options.conformant): the standard's interval rule instead of the reference's
 };
 
-// WRITE: the lane's records waiting for their 16-byte store (shift register: r3 is the newest), and
-// where the outputs go.  Every lane's run of records starts at a multiple of HJD_REC_RUN, so a full burst is
-// two aligned global_store_dwordx4 back to back: one 32-byte sector.
+// WRITE: where the outputs go.  A lane's records wait for their store in its column of an LDS ring (word k of the burst at
+// ring[k * HJD_WRITE_WG]): every lane's run of records starts at a multiple of HJD_REC_RUN, so a full burst is two aligned
+// global_store_dwordx4 back to back, one 32-byte sector.  (Until round 3 the burst was a shift register of eight VGPRs: fourteen
+// v_mov per loop iteration around the record branch, whether the iteration produced a record or not.)
 struct WriteCtx {
-    uint32_t r0, r1, r2, r3; // the newest four records (shift register: r3 is the newest)
-    uint4 h;                 // the four before them, once a run's first half is complete
+    uint32_t *ring;
     uint32_t *rec;
     uint32_t rec_cap;
     uint4 *blk;
@@ -350,22 +350,15 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             } else {
                 W.mask |= 1ull << slot;
             }
-            W.r0 = W.r1;
-            W.r1 = W.r2;
-            W.r2 = W.r3;
-            W.r3 = w;
             static_assert(HJD_REC_RUN == 8, "two 16-byte halves per burst");
-            if ((nrec & 3u) == 3u) { // four more records complete
-                if (nrec & 4u) { // ... and with them a burst of eight: one 32-byte sector
-                    if (nrec < W.rec_cap) {
-                        uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - 7u));
-                        dst[0] = W.h;
-                        dst[1] = make_uint4(W.r0, W.r1, W.r2, W.r3);
-                    } else {
-                        flags |= HJD_FLAG_OVERRUN;
-                    }
+            W.ring[(nrec & 7u) * HJD_WRITE_WG] = w;
+            if ((nrec & 7u) == 7u) { // a burst of eight is complete: one 32-byte sector
+                if (nrec < W.rec_cap) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - 7u));
+                    dst[0] = make_uint4(W.ring[0], W.ring[HJD_WRITE_WG], W.ring[2 * HJD_WRITE_WG], W.ring[3 * HJD_WRITE_WG]);
+                    dst[1] = make_uint4(W.ring[4 * HJD_WRITE_WG], W.ring[5 * HJD_WRITE_WG], W.ring[6 * HJD_WRITE_WG], W.ring[7 * HJD_WRITE_WG]);
                 } else {
-                    W.h = make_uint4(W.r0, W.r1, W.r2, W.r3);
+                    flags |= HJD_FLAG_OVERRUN;
                 }
             }
             nrec++;
@@ -933,7 +926,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t *s_w = s_dyn + P.lds_state_word;
     uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_w + 48);
-    uint32_t *s_rows = s_w + 64;
+    uint32_t *s_ring = s_w + 64;                        // [HJD_REC_RUN][HJD_WRITE_WG]: the lanes' bursts in the making
+    uint32_t *s_rows = s_ring + HJD_REC_RUN * HJD_WRITE_WG;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits, wps = S >> 5, nph = wps / P.phase_words;
@@ -1018,7 +1012,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         }
     }
 
-    WriteCtx W = {HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, make_uint4(HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD), P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
+    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
                   im.nblocks, s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
     W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
@@ -1051,18 +1045,11 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the span ends inside a block it owns
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
-        for (uint32_t q = k & 3u; q != 0u && q < 4u; q++) { // bring the newest 1..3 records to the front of their half
-            W.r0 = W.r1;
-            W.r1 = W.r2;
-            W.r2 = W.r3;
-            W.r3 = HJD_REC_PAD;
-        }
-        const uint4 pad = make_uint4(HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD, HJD_REC_PAD), r = make_uint4(W.r0, W.r1, W.r2, W.r3);
-        const uint4 first = k < 4u ? r : W.h, second = k <= 4u ? pad : r;
+        for (uint32_t q = k; q < HJD_REC_RUN; q++) W.ring[q * HJD_WRITE_WG] = HJD_REC_PAD;
         if (nrec + HJD_REC_RUN - k <= im.rec_cap) {
             uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - k));
-            dst[0] = first;
-            dst[1] = second;
+            dst[0] = make_uint4(W.ring[0], W.ring[HJD_WRITE_WG], W.ring[2 * HJD_WRITE_WG], W.ring[3 * HJD_WRITE_WG]);
+            dst[1] = make_uint4(W.ring[4 * HJD_WRITE_WG], W.ring[5 * HJD_WRITE_WG], W.ring[6 * HJD_WRITE_WG], W.ring[7 * HJD_WRITE_WG]);
         } else {
             flags |= HJD_FLAG_OVERRUN;
         }

@@ -668,8 +668,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_bytes_sync = (P.lds_state_word_s + 7 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
-        // k_write: scan scratch, slot table, block table, then the workgroup's rows ([word][row], rows + 1 apart)
-        P.lds_bytes_write = (P.lds_state_word + 64 + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
+        // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
+        P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
 
