@@ -33,7 +33,9 @@
 #ifndef HJD_SYNC_WG
 #define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
 #endif
+#ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
+#endif
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 
