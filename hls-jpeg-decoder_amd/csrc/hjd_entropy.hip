@@ -736,6 +736,45 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     __syncthreads();
     stamp(3); // everybody's
 
+    // Uniform images.  Every 4:2:0 MCU of a uniform frame is the same 32 bits with the standard tables, so the stream is one word
+    // repeated; on such a stream a guessed decode either falls into step within a few symbols or locks into a wrong cycle for
+    // good, depending only on the bit phase it starts at — 12 of the 32 phases never fall into step, all subsequences share ONE
+    // phase, and white and black frames have an unlucky one: no checkpoint is ever met and a single lane walks the true state
+    // through the whole scan (a white 4K frame: 58 ms instead of 0.3).  But a decode is a function of (the words, the start state),
+    // so across a RUN of subsequences that consist of one and the same word (their two look-ahead words included) nothing needs
+    // decoding twice: if the run's first subsequence a carried its start state over unchanged (end = start + S bits, same z, m),
+    // then subsequence j of the run, started from a's state moved (j - a) S bits on — which is what its predecessor hands it —
+    // has a's checkpoints and counts, moved on by the same distance.  `elig`: this slot continues such a run; `head`: the run's
+    // first slot.  (Restart streams: their markers are not in the words; left to the ordinary rounds.)
+    static_assert(T / 64 <= 8, "s_wc[8..15] hold the waves' run heads");
+    bool elig = false, any_elig = false; // any_elig: some slot of this workgroup continues a run (ordinary content: none)
+    uint32_t head = 0;
+    if (!im.restart) {
+        uint32_t cw = 0;
+        bool ce = valid && (i + 1u) * S <= total_bits;
+        const uint32_t *rw = row_base(E.wbase, i, P.log2_words);
+        if (ce) cw = rw[0];
+        for (uint32_t k = 1; k < (S >> 5) + 2u && __any(ce); k++) // leaves at the first word on ordinary content
+            if (ce) ce = rw[(size_t)k * 64u] == cw;
+        s_lp[tid] = cw;
+        s_lst[tid] = ce ? 1u : 0u;
+        __syncthreads();
+        elig = ce && tid > 0u && s_lst[tid - 1u] != 0u && s_lp[tid - 1u] == cw;
+        const unsigned long long nb0 = __ballot(!elig);
+        if (lane == 0) s_wc[8u + wv] = nb0 ? wv * 64u + 63u - (uint32_t)__clzll((long long)nb0) : 0xFFFFFFFFu;
+        any_elig = __syncthreads_or(elig ? 1 : 0) != 0; // also: s_lp / s_lst are the work list from here on
+        const unsigned long long below = nb0 & (~0ull >> (63u - lane));
+        if (below) {
+            head = wv * 64u + 63u - (uint32_t)__clzll((long long)below);
+        } else {
+            for (uint32_t q = wv; q-- > 0u;)
+                if (s_wc[8u + q] != 0xFFFFFFFFu) {
+                    head = s_wc[8u + q];
+                    break;
+                }
+        }
+    }
+
     uint32_t rounds = 0;
     bool tables_loaded = MODE == 0;
     for (; rounds < 96u; rounds++) {
@@ -745,22 +784,54 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             wp = 0;
             wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
         }
-        const bool dirty = valid && (wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid]);
+        bool dirty = valid && (wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid]);
+        bool moved = false; // this slot takes its run head's record, moved on, instead of being decoded
+        if (any_elig) {
+            s_lp[tid] = dirty ? 1u : 0u;
+            __syncthreads();
+            if (elig && s_lp[head] == 0u) { // the head's record is not about to change
+                const uint32_t ua = s_up[head], ea = s_ep[head], za = s_uzm[head];
+                if (ea == ua + S && (uint32_t)s_ezm[head] == za) {
+                    wp = ea + (tid - head - 1u) * S;
+                    wzm = za;
+                    moved = wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid] || s_ep[tid] != wp + S || (uint32_t)s_ezm[tid] != wzm;
+                    dirty = false;
+                }
+            }
+            __syncthreads(); // the flags have been read: s_lp is the work list again
+        }
         unsigned long long bal = __ballot(dirty);
-        if (lane == 0) s_wc[wv] = (uint32_t)__popcll(bal);
+        const bool any_moved = __any(moved);
+        if (lane == 0) s_wc[wv] = (uint32_t)__popcll(bal) | (any_moved ? 0x10000u : 0u);
         __syncthreads();
         uint32_t base = 0, n = 0;
 #pragma unroll
         for (uint32_t q = 0; q < T / 64; q++) {
             const uint32_t c = s_wc[q];
-            base += q < wv ? c : 0u;
+            base += q < wv ? c & 0xFFFFu : 0u;
             n += c;
         }
         if (n == 0) break;
+        n &= 0xFFFFu; // bits 16..: some slot is moved this round (another round then checks the chain)
         if (MODE != 0 && !tables_loaded) {
             load_tables<true>(ts, s_lut, s_sec);
             tables_loaded = true;
         }
+        if (moved) {
+            const uint32_t d = (tid - head) * S;
+            for (uint32_t ph = 0; ph < nph; ph++) {
+                const uint2 c = *ck(ph, head);
+                *ck(ph, tid) = make_uint2(c.x + d, c.y);
+            }
+            s_up[tid] = wp;
+            s_uzm[tid] = (uint16_t)wzm;
+            s_ep[tid] = wp + S;
+            s_ezm[tid] = (uint16_t)wzm;
+            s_cnt[tid] = s_cnt[head];
+        }
+        // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's head with a new state would go on
+        // through the whole run, one lane, window after window — the run takes the head's new record in the next round instead.
+        if (elig) s_mark[tid] = rounds + 1u;
         if (dirty) {
             const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             s_lp[t] = wp;

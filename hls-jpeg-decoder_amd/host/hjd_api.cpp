@@ -1249,7 +1249,12 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             bool stale = false;
             for (auto &st : b->state) stale |= (st.flags & HJD_FLAG_NOT_CONVERGED) != 0;
             if (!stale) break;
-            if (attempt >= 4096) {
+            if (getenv("HJD_VERBOSE"))
+                for (size_t k = 0; k < b->state.size(); k++)
+                    if (b->state[k].flags & HJD_FLAG_NOT_CONVERGED)
+                        fprintf(stderr, "hjd: attempt %d image %zu flags %#x sync rounds %u (max %u) decodes %u\n", attempt, k, b->state[k].flags,
+                                b->state[k].sync_iters, b->state[k].sync_iters_max, b->state[k].sync_decodes);
+            if (attempt >= (getenv("HJD_MAX_RESYNC") ? atoi(getenv("HJD_MAX_RESYNC")) : 4096)) { // (the knob: diagnostics)
                 overall = HJD_ERR_INTERNAL;
                 break;
             }

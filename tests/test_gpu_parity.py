@@ -317,6 +317,35 @@ def test_extreme_aspect_ratios(hjd, dec):
         assert orc == 0 and outs[0].tobytes() == T.oracle_bmp(orgb), (w, h)
 
 
+def test_uniform_frames(hjd):
+    """Uniform images: every MCU is the same few bits, the stream is periodic, and a guessed decode may lock into a wrong cycle
+    for good (white and black 4:2:0 frames with the standard tables do: all subsequences start at one and the same unlucky bit
+    phase).  The bytes must be the oracle's whatever the subsequence size; with one synchronisation workgroup per image the run of
+    identical subsequences is resolved by moving the first one's record along (sync_body), not by one lane walking the whole
+    scan: no host re-synchronisation and a handful of refinement rounds."""
+    frames = []
+    for val in (255, 0, 200, 17):
+        for hf, vf in ((2, 2), (1, 1), (2, 1)):
+            frames.append(T.encode_jpeg(np.full((1080, 1920, 3), val, np.uint8), 85, hf, vf))
+    half = T.synth_rgb(1920, 1080, 77, 6.0)
+    half[300:900] = 255  # a uniform band between textured parts
+    frames.append(T.encode_jpeg(half, 85, 2, 2))
+    want = [T.oracle_decode(j)[1] for j in frames]
+    for bits in (0, 256, 4096):
+        d = hjd.Decoder(0, subseq_bits=bits)
+        b = d.prepare(frames)
+        b.run()
+        st = b.finish()
+        assert st == [0] * len(frames), (bits, st)
+        for k in range(len(frames)):
+            assert np.array_equal(b.download(k), want[k]), (bits, k)
+        if bits != 256:  # 1080p: one synchronisation workgroup per image at 2048 bits and more
+            assert b.resync_count() == 0, bits
+            assert max(b.sync_stats(k)["iters_max"] for k in range(len(frames))) <= 8, [b.sync_stats(k) for k in range(len(frames))]
+        b.close()
+        d.close()
+
+
 def test_bit_flipped_scans_never_crash_and_never_lie(hjd, dec):
     """Corrupt entropy data: the GPU path must terminate, and whenever it reports success its bytes
     must be the oracle's (which restates what the reference computes on that exact stream); whenever the
