@@ -736,30 +736,51 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     __syncthreads();
     stamp(3); // everybody's
 
-    // Uniform images.  Every 4:2:0 MCU of a uniform frame is the same 32 bits with the standard tables, so the stream is one word
-    // repeated; on such a stream a guessed decode either falls into step within a few symbols or locks into a wrong cycle for
-    // good, depending only on the bit phase it starts at — 12 of the 32 phases never fall into step, all subsequences share ONE
-    // phase, and white and black frames have an unlucky one: no checkpoint is ever met and a single lane walks the true state
-    // through the whole scan (a white 4K frame: 58 ms instead of 0.3).  But a decode is a function of (the words, the start state),
-    // so across a RUN of subsequences that consist of one and the same word (their two look-ahead words included) nothing needs
-    // decoding twice: if the run's first subsequence a carried its start state over unchanged (end = start + S bits, same z, m),
-    // then subsequence j of the run, started from a's state moved (j - a) S bits on — which is what its predecessor hands it —
-    // has a's checkpoints and counts, moved on by the same distance.  `elig`: this slot continues such a run; `head`: the run's
-    // first slot.  (Restart streams: their markers are not in the words; left to the ordinary rounds.)
+    // Uniform regions.  Every MCU of a uniform image is the same few bits (4:2:0 with the standard tables: 32; with tables
+    // optimised for the image 12 or less), so the stream is periodic, and on a periodic stream a guessed decode either falls into
+    // step within a few symbols or locks into a wrong cycle for good, depending only on the bit phase it starts at (standard
+    // tables, 4:2:0: 12 of the 32 phases never fall into step, all subsequences share ONE phase, white and black frames have an
+    // unlucky one).  Then no checkpoint is ever met and a single lane walks the true state through the whole region (a white 4K
+    // frame: 58 ms instead of 0.3; optimised tables: 60-130 ms).  But a decode is a function of (the words, the start state):
+    // where subsequence j consists of the same words as subsequence j - q (its two look-ahead words included) and is handed the
+    // start state of j - d moved d S bits on, d a multiple of q, it has j - d's checkpoints, counts and end state, moved on by
+    // the same distance, and nothing needs decoding.  That is exact whatever the states are; it resolves a whole run in one
+    // round once the run's first d subsequences are settled and the state has come round after them (end of the d-th = start of
+    // the first + d S bits, same z and m: d S is then a multiple of the MCU's length).
+    //   runq : the distance q (one per workgroup: the smallest any slot found, 1 for a stream of one repeated word)
+    //   elig : this slot's words equal those of the slot runq before it;  head : the nearest slot at or below that is not elig
+    //   (the run's first runq slots end there).  Restart streams: their markers are not in the words; left to the ordinary rounds.
+#ifndef HJD_RUN_Q
+#define HJD_RUN_Q 32u // distances tried (the odd part of the MCU's bit length, in practice)
+#define HJD_RUN_D 96u // longest state period, in subsequences
+#endif
     static_assert(T / 64 <= 8, "s_wc[8..15] hold the waves' run heads");
     bool elig = false, any_elig = false; // any_elig: some slot of this workgroup continues a run (ordinary content: none)
-    uint32_t head = 0;
+    uint32_t head = 0, runq = 0;
     if (!im.restart) {
-        uint32_t cw = 0;
-        bool ce = valid && (i + 1u) * S <= total_bits;
+        const bool full = valid && (i + 1u) * S <= total_bits;
+        const uint32_t nwords = (S >> 5) + 2u;
         const uint32_t *rw = row_base(E.wbase, i, P.log2_words);
-        if (ce) cw = rw[0];
-        for (uint32_t k = 1; k < (S >> 5) + 2u && __any(ce); k++) // leaves at the first word on ordinary content
-            if (ce) ce = rw[(size_t)k * 64u] == cw;
-        s_lp[tid] = cw;
-        s_lst[tid] = ce ? 1u : 0u;
+        const uint32_t w0 = full ? rw[0] : 0u;
+        uint32_t myq = 0;
+        for (uint32_t q = 1; q <= HJD_RUN_Q; q++) { // ordinary content: one load and one comparison per distance
+            bool c = full && myq == 0u && tid >= q;
+            if (!__any(c)) break;
+            const uint32_t *rp = rw - q; // row i - q: the rows of a group of 64 lie side by side ...
+            if (c) {
+                rp = row_base(E.wbase, i - q, P.log2_words); // ... but the group may change
+                c = rp[0] == w0;
+            }
+            for (uint32_t k = 1; k < nwords && __any(c); k++)
+                if (c) c = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
+            if (c) myq = q;
+        }
+        if (tid == 0) s_lst[0] = 0xFFFFFFFFu;
         __syncthreads();
-        elig = ce && tid > 0u && s_lst[tid - 1u] != 0u && s_lp[tid - 1u] == cw;
+        if (myq) atomicMin(&s_lst[0], myq);
+        __syncthreads();
+        runq = s_lst[0];
+        elig = myq != 0u && myq == runq;
         const unsigned long long nb0 = __ballot(!elig);
         if (lane == 0) s_wc[8u + wv] = nb0 ? wv * 64u + 63u - (uint32_t)__clzll((long long)nb0) : 0xFFFFFFFFu;
         any_elig = __syncthreads_or(elig ? 1 : 0) != 0; // also: s_lp / s_lst are the work list from here on
@@ -785,16 +806,31 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
         }
         bool dirty = valid && (wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid]);
-        bool moved = false; // this slot takes its run head's record, moved on, instead of being decoded
+        bool moved = false; // this slot takes the record of a settled slot of its run, moved on, instead of being decoded
+        uint32_t src = 0, shift = 0, mep = 0, mezm = 0;
         if (any_elig) {
             s_lp[tid] = dirty ? 1u : 0u;
             __syncthreads();
-            if (elig && s_lp[head] == 0u) { // the head's record is not about to change
-                const uint32_t ua = s_up[head], ea = s_ep[head], za = s_uzm[head];
-                if (ea == ua + S && (uint32_t)s_ezm[head] == za) {
-                    wp = ea + (tid - head - 1u) * S;
-                    wzm = za;
-                    moved = wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid] || s_ep[tid] != wp + S || (uint32_t)s_ezm[tid] != wzm;
+            if (elig) {
+                const uint32_t a = head + 1u - runq; // the run's first slot (slots below runq are never elig: a >= 0)
+                uint32_t dsel = 0;
+                bool settled = true; // slots [a, a + d): their records are not about to change, each starts where the one before ends
+                for (uint32_t d = runq; d <= HJD_RUN_D && a + d <= tid && settled; d += runq) {
+                    for (uint32_t x = a + d - runq; x < a + d; x++) settled = settled && s_lp[x] == 0u;
+                    if (settled && s_ep[a + d - 1u] == s_up[a] + d * S && s_ezm[a + d - 1u] == s_uzm[a]) { // the state has come round
+                        dsel = d;
+                        break;
+                    }
+                }
+                if (dsel) {
+                    const uint32_t t = tid - a;
+                    src = a + t % dsel;
+                    shift = (t / dsel) * dsel * S;
+                    wp = s_up[src] + shift;
+                    wzm = s_uzm[src];
+                    mep = s_ep[src] + shift;
+                    mezm = s_ezm[src];
+                    moved = wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid] || mep != s_ep[tid] || mezm != (uint32_t)s_ezm[tid];
                     dirty = false;
                 }
             }
@@ -818,19 +854,18 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             tables_loaded = true;
         }
         if (moved) {
-            const uint32_t d = (tid - head) * S;
             for (uint32_t ph = 0; ph < nph; ph++) {
-                const uint2 c = *ck(ph, head);
-                *ck(ph, tid) = make_uint2(c.x + d, c.y);
+                const uint2 c = *ck(ph, src);
+                *ck(ph, tid) = make_uint2(c.x + shift, c.y);
             }
             s_up[tid] = wp;
             s_uzm[tid] = (uint16_t)wzm;
-            s_ep[tid] = wp + S;
-            s_ezm[tid] = (uint16_t)wzm;
-            s_cnt[tid] = s_cnt[head];
+            s_ep[tid] = mep;
+            s_ezm[tid] = (uint16_t)mezm;
+            s_cnt[tid] = s_cnt[src];
         }
-        // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's head with a new state would go on
-        // through the whole run, one lane, window after window — the run takes the head's new record in the next round instead.
+        // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's first slots with a new state would go
+        // on through the whole run, one lane, window after window — the run takes the new records in the next round instead.
         if (elig) s_mark[tid] = rounds + 1u;
         if (dirty) {
             const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));

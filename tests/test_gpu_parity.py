@@ -321,12 +321,16 @@ def test_uniform_frames(hjd):
     """Uniform images: every MCU is the same few bits, the stream is periodic, and a guessed decode may lock into a wrong cycle
     for good (white and black 4:2:0 frames with the standard tables do: all subsequences start at one and the same unlucky bit
     phase).  The bytes must be the oracle's whatever the subsequence size; with one synchronisation workgroup per image the run of
-    identical subsequences is resolved by moving the first one's record along (sync_body), not by one lane walking the whole
-    scan: no host re-synchronisation and a handful of refinement rounds."""
+    identical subsequences is resolved by moving the first ones' records along (sync_body), not by one lane walking the whole
+    scan: no host re-synchronisation and a handful of refinement rounds (a few more where the decoder's state only comes round
+    after several subsequences)."""
     frames = []
     for val in (255, 0, 200, 17):
         for hf, vf in ((2, 2), (1, 1), (2, 1)):
             frames.append(T.encode_jpeg(np.full((1080, 1920, 3), val, np.uint8), 85, hf, vf))
+    for mode in (T.HUFF_FOUR_OPTIMISED, T.HUFF_SIX_OPTIMISED):  # one- and two-bit codes: MCUs of 6 or 12 bits, periods of three words
+        for hf, vf in ((2, 2), (1, 1), (4, 1)):
+            frames.append(T.encode_jpeg_ex(np.full((1080, 1920, 3), 255, np.uint8), 85, hf, vf, huff_mode=mode))
     half = T.synth_rgb(1920, 1080, 77, 6.0)
     half[300:900] = 255  # a uniform band between textured parts
     frames.append(T.encode_jpeg(half, 85, 2, 2))
@@ -341,7 +345,7 @@ def test_uniform_frames(hjd):
             assert np.array_equal(b.download(k), want[k]), (bits, k)
         if bits != 256:  # 1080p: one synchronisation workgroup per image at 2048 bits and more
             assert b.resync_count() == 0, bits
-            assert max(b.sync_stats(k)["iters_max"] for k in range(len(frames))) <= 8, [b.sync_stats(k) for k in range(len(frames))]
+            assert max(b.sync_stats(k)["iters_max"] for k in range(len(frames))) <= 16, [b.sync_stats(k) for k in range(len(frames))]
         b.close()
         d.close()
 

@@ -17,8 +17,11 @@ cases["white 4:4:4"] = (white, 1, 1)
 cases["white 4:2:2"] = (white, 2, 1)
 nz = np.clip(T.synth_rgb(W, H, 7, 0.5).astype(np.int16) - 118, 0, 255).astype(np.uint8)  # nearly black, a little texture
 cases["dark, faint texture"] = (nz, 2, 2)
-for name, (rgb, hf, vf) in cases.items():
-    j = T.encode_jpeg(rgb, 85, hf, vf)
+cases = {k: v + (T.HUFF_STD,) for k, v in cases.items()}
+cases["white, optimised tables"] = (white, 2, 2, T.HUFF_FOUR_OPTIMISED)        # one-bit codes: MCUs of 12 bits, a period of three words
+cases["white 4:4:4, optimised"] = (white, 1, 1, T.HUFF_SIX_OPTIMISED)
+for name, (rgb, hf, vf, mode) in cases.items():
+    j = T.encode_jpeg_ex(rgb, 85, hf, vf, huff_mode=mode)
     for S in (0,):
         d = hjd.Decoder(0, subseq_bits=S)
         b = d.prepare([j])
@@ -27,6 +30,6 @@ for name, (rgb, hf, vf) in cases.items():
         stg = b.run_timed(); st2 = b.finish()
         out = b.download(0) if st == [0] else None
         ok = out is not None and np.array_equal(out, hjd.__dict__.get("_none", out))
-        print("%-20s S=%-5s scan %7d B  status %s  wall %.2f / %.2f ms  resyncs %d  stages %s" % (
+        print("%-26s S=%-5s scan %7d B  status %s  wall %.2f / %.2f ms  resyncs %d  stages %s" % (
             name, S or "auto", len(j), st, t1 * 1e3, t2 * 1e3, b.resync_count(), " ".join("%s=%.3f" % (k, t) for k, t in stg)), flush=True)
         b.close(); d.close()
