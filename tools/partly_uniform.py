@@ -1,6 +1,6 @@
 """Partly uniform 4K content (objects on a white background, flat patches, bands), standard and optimised tables."""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch  # noqa
