@@ -762,15 +762,20 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         const uint32_t nwords = (S >> 5) + 2u;
         const uint32_t *rw = row_base(E.wbase, i, P.log2_words);
         const uint32_t w0 = full ? rw[0] : 0u;
+        // distances at which the first word agrees (independent loads: one round trip for all of them) ...
+        static_assert(HJD_RUN_Q <= 32, "one bit per distance");
+        uint32_t cm = 0;
+        if (full) {
+            const uint32_t qn = min(tid, HJD_RUN_Q);
+            for (uint32_t q = 1; q <= qn; q++) cm |= (row_base(E.wbase, i - q, P.log2_words)[0] == w0 ? 1u : 0u) << (q - 1u);
+        }
+        // ... and of those the smallest at which every word does (ordinary content: none to try)
         uint32_t myq = 0;
-        for (uint32_t q = 1; q <= HJD_RUN_Q; q++) { // ordinary content: one load and one comparison per distance
-            bool c = full && myq == 0u && tid >= q;
-            if (!__any(c)) break;
-            const uint32_t *rp = rw - q; // row i - q: the rows of a group of 64 lie side by side ...
-            if (c) {
-                rp = row_base(E.wbase, i - q, P.log2_words); // ... but the group may change
-                c = rp[0] == w0;
-            }
+        while (__any(cm != 0u && myq == 0u)) {
+            bool c = cm != 0u && myq == 0u;
+            const uint32_t q = c ? (uint32_t)__ffs((int)cm) : 1u;
+            cm &= cm - 1u;
+            const uint32_t *rp = c ? row_base(E.wbase, i - q, P.log2_words) : rw;
             for (uint32_t k = 1; k < nwords && __any(c); k++)
                 if (c) c = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
             if (c) myq = q;
