@@ -26,7 +26,8 @@ for k in range(32):  # 32 distinct images: size x sampling x (no DRI | DRI)
 src = [T.synth_jpeg(*s) for s in specs]
 jpgs = [src[k % 32] for k in range(128)]
 pixels = sum(specs[k % 32][0] * specs[k % 32][1] for k in range(128))
-dec = hjd.Decoder(0)
+NSTREAMS = next((int(a.split('=')[1]) for a in sys.argv if a.startswith('streams=')), 0)  # streams=N: the batch split over N streams inside the library (hjd_options.streams)
+dec = hjd.Decoder(0, streams=NSTREAMS)
 b = dec.prepare(jpgs)
 assert all(s == 0 for s in b.parse_status)
 for _ in range(3):
@@ -53,7 +54,7 @@ for k in range(32):
 px, alg, scan = b.totals()
 print(json.dumps({"metric": "Mpixels/s JPEG->RGB", "config": {"workload": "BASELINE config 5: one batch of 128 images, 8 sizes 3840x2160..250x187, "
                   "4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1, half of them with DRI (intervals of %s), resident in HBM, RGB to HBM" % ("one MCU row, four rows, 7 MCUs, 1 MCU" if "hostile" in sys.argv else "one MCU row, four rows, two rows, 16 MCUs"),
-                  "images": 128, "distinct_images": 32, "with_dri": sum(1 for s in specs if s[6]) * 4, "scan_bytes": scan},
+                  "images": 128, "distinct_images": 32, "internal_streams": NSTREAMS, "with_dri": sum(1 for s in specs if s[6]) * 4, "scan_bytes": scan},
                   "value": round(pixels / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 4), "steps": STEPS,
                   "pipeline_frac_of_hbm_peak": round(alg / dt / 8e12, 5), "sequential_emulations": b.sequential_count(), "resyncs": b.resync_count(),
                   "parity": "bit-exact vs oracle on %d of 32 distinct images (the others are refused by both)" % ok}))
