@@ -480,7 +480,7 @@ struct RowEnv {
 
 template <class AfterPhase>
 __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
-                                                uint32_t &nblk, uint32_t &nrec, AfterPhase after_phase)
+                                                uint32_t &nblk, uint32_t &nrec, uint32_t &mk0, AfterPhase after_phase)
 {
     const HjdParams &P = *E.P;
     const HjdImage &im = *E.im;
@@ -497,6 +497,7 @@ __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, ui
             else hi = mid;
         }
         rc.mk = lo;
+        mk0 = lo; // kept per subsequence (sync_body): refinement walks, repair launches and k_write start their marker scan here
     }
     const uint32_t nph = (1u << lw) / WPP;
     const uint32_t *src0 = row_base(E.wbase, i, lw);
@@ -522,8 +523,11 @@ __device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, ui
 // The same for ONE staging window (phase ph) of subsequence i — synchronisation only: the work items of a refinement
 // round advance a window at a time, so that those whose state has fallen into step with the subsequence's previous decode
 // can drop out (sync_body).
+// `mk` (restart streams): in, an index at or before the first marker past p (0xFFFFFFFF: none known, search for it); out, the
+// scan's position after the window — a walk carries it from window to window (a binary search per window was 13 dependent
+// global loads for an image with 8000 markers).
 __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, uint32_t i, uint32_t ph, uint32_t &p, uint32_t &z, uint32_t &m,
-                                                  uint32_t &nblk, uint32_t &nrec)
+                                                  uint32_t &nblk, uint32_t &nrec, uint32_t &mk)
 {
     const HjdParams &P = *E.P;
     const HjdImage &im = *E.im;
@@ -539,14 +543,18 @@ __device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, 
     for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
     if (im.restart) {
         rc.nmark = E.nmark;
-        uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rc.mpos[mid] <= p) lo = mid + 1;
-            else hi = mid;
+        if (mk == 0xFFFFFFFFu) {
+            uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rc.mpos[mid] <= p) lo = mid + 1;
+                else hi = mid;
+            }
+            mk = lo;
         }
-        rc.mk = lo;
+        rc.mk = min(mk, rc.nmark); // sync_span moves it past p
         sync_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
+        mk = rc.mk;
     } else {
         sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
     }
@@ -633,7 +641,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     uint32_t *s_lst = s_lp + T;                  //   z | m << 6 | slot << 9
     uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_lst + T); // ... end state z | m << 8
     uint16_t *s_uzm = s_ezm + T;                               // ... start state z | m << 8
-    uint32_t *s_wc = s_lst + 2 * T;              // work items per wave
+    uint32_t *s_mk0 = s_lst + 2 * T;             // restart streams: index of the first marker past the slot's first bit
+    uint32_t *s_wc = s_lst + 3 * T;              // work items per wave
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 16);
     uint32_t *s_rows = s_wc + 32;
     const HjdTableSet *ts = &P.tabs[im.tabset];
@@ -686,7 +695,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         if (nw != 0u) {
             const bool wu = valid && i > 0u;
             p = sp - nw * P.phase_words * 32u;
-            for (uint32_t ph = nph - nw; ph < nph; ph++) decode_phase_sync(E, wu, i - 1u, ph, p, z, m, nblk, nrec);
+            uint32_t wmk = 0xFFFFFFFFu;
+            for (uint32_t ph = nph - nw; ph < nph; ph++) decode_phase_sync(E, wu, i - 1u, ph, p, z, m, nblk, nrec, wmk);
             if (!wu || p < sp || p >= sp + 32u) { // no predecessor, or a marker jump took the walk elsewhere: the plain guess
                 p = sp;
                 z = 0;
@@ -700,7 +710,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         s_uzm[tid] = (uint16_t)(z | (m << 8));
         ext_p = p; // slot 0 has no predecessor inside the workgroup: its start state stands (the warm-up slots are there for that)
         ext_zm = z | (m << 8);
-        decode_row_sync(E, valid, i, p, z, m, nblk, nrec, [&](uint32_t ph) {
+        uint32_t mk0 = 0;
+        decode_row_sync(E, valid, i, p, z, m, nblk, nrec, mk0, [&](uint32_t ph) {
             if (valid) *ck(ph, tid) = make_uint2(p, z | (m << 6) | ((nblk - cb) << 9) | ((nrec - cr) << 20));
             cb = nblk;
             cr = nrec;
@@ -708,6 +719,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         s_ep[tid] = p;
         s_ezm[tid] = (uint16_t)(z | (m << 8));
         s_cnt[tid] = nblk | (nrec << 16);
+        s_mk0[tid] = mk0;
+        if (im.restart && owned) P.submk[g] = mk0;
         ndec_total = lim > row0 ? lim - row0 : 0u;
         nphase_items = valid ? nw : 0u;
     } else {
@@ -717,6 +730,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             r = P.substate[g];
             c = P.subcnt[g];
         }
+        s_mk0[tid] = valid && im.restart ? P.submk[g] : 0u;
         s_ep[tid] = r.x;
         s_ezm[tid] = (uint16_t)r.y;
         s_cnt[tid] = c;
@@ -890,11 +904,12 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             uint32_t slot = st >> 9, ph = 0u;
             uint32_t p = live ? s_lp[tid] : 0u, z = st & 63u, m = (st >> 6) & 7u;
             uint32_t cn = 0u, co = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
+            uint32_t wmk = live ? s_mk0[slot] : 0u; // the walk's marker scan: never behind the state's position, which only grows
             for (uint32_t step = 0; __any(live) && step < 65536u; step++) {
                 uint2 old = make_uint2(0xFFFFFFFFu, 0u);
                 if (live) old = *ck(ph, slot); // arrives while the window is decoded
                 uint32_t nblk = 0, nrec = 0;
-                decode_phase_sync(E, live, row0 + slot, ph, p, z, m, nblk, nrec);
+                decode_phase_sync(E, live, row0 + slot, ph, p, z, m, nblk, nrec, wmk);
                 steps_done++;
                 if (live) {
                     nphase_items++;
@@ -1136,13 +1151,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u, im.conformant};
         if (im.restart) {
             rc.nmark = min(P.st[ii].nmarkers, im.mark_cap);
-            uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rc.mpos[mid] <= p) lo = mid + 1;
-                else hi = mid;
-            }
-            rc.mk = lo;
+            rc.mk = min(P.submk[g], rc.nmark); // first marker past the subsequence's first bit (k_sync); write_span moves it past p
             write_span<true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
         } else {
             write_span<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);

@@ -17,6 +17,7 @@ struct HjdParams {
     uint8_t *mval;             // marker codes
     uint4 *substate;           // per subsequence: end state, start state used
     uint32_t *subcnt;          // per subsequence: blocks | records << 16
+    uint32_t *submk;           // per subsequence of a restart stream: index of the first marker past its first bit
     unsigned long long *dbg;   // diagnostics (HJD_SYNC_PROF=1): 32 words per synchronisation workgroup, else null
     uint2 *ckpt;               // checkpoints, per image [window][subsequence]: x = bit position at the window's end, y = z | m << 6 |
                                // blocks inside the window << 9 | records inside it << 20; after ck_scratch entries: k_sync's

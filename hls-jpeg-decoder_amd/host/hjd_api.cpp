@@ -178,6 +178,7 @@ struct hjd_batch {
     uint32_t *d_chunk_kept = nullptr;
     uint4 *d_substate = nullptr;
     uint32_t *d_subcnt = nullptr;
+    uint32_t *d_submk = nullptr; // restart streams: per subsequence, index of the first marker past its first bit (k_sync -> k_write, repair)
     uint2 *d_ckpt = nullptr;
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
@@ -440,6 +441,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_chunk_kept);
     (void)hipFree(b->d_substate);
     (void)hipFree(b->d_subcnt);
+    (void)hipFree(b->d_submk);
     (void)hipFree(b->d_ckpt);
     (void)hipFree(b->d_dbg);
     (void)hipFree(b->d_wgsum);
@@ -667,7 +669,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_bytes_sync = (P.lds_state_word_s + 7 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_sync = (P.lds_state_word_s + 8 * HJD_SYNC_WG + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
         P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
@@ -687,6 +689,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_mval, b->nmarks + 1));
     need(slab_reserve(b, b->d_substate, sizeof(uint4) * b->nsub));
     need(slab_reserve(b, b->d_subcnt, sizeof(uint32_t) * b->nsub));
+    need(slab_reserve(b, b->d_submk, sizeof(uint32_t) * b->nsub));
     P.ck_scratch = (uint64_t)b->nsub * nph; // canonical entries first, then k_sync's private ones for its warm-up slots
     need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * ((size_t)b->nsub * nph + (size_t)b->nsyncwg * nph * K + 1)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
@@ -771,6 +774,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     HIPCHK(hipMemsetAsync(b->d_st, 0, sizeof(HjdImageState) * b->nimg, up));
     HIPCHK(hipMemsetAsync(b->d_substate, 0, sizeof(uint4) * (b->nsub ? b->nsub : 1), up));
     HIPCHK(hipMemsetAsync(b->d_subcnt, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1), up));
+    HIPCHK(hipMemsetAsync(b->d_submk, 0, sizeof(uint32_t) * (b->nsub ? b->nsub : 1), up));
 
     P.img = b->d_img;
     P.st = b->d_st;
@@ -783,6 +787,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.mval = b->d_mval;
     P.substate = b->d_substate;
     P.subcnt = b->d_subcnt;
+    P.submk = b->d_submk;
     P.ckpt = b->d_ckpt;
     P.dbg = nullptr;
     if (getenv("HJD_SYNC_PROF")) {
