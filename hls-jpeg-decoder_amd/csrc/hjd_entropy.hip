@@ -636,15 +636,19 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     uint32_t *s_ep = s_dyn + P.lds_state_word_s; // end state: bit position ...
     uint32_t *s_up = s_ep + T;                   // the start state that end state was computed from: bit position ...
     uint32_t *s_cnt = s_up + T;                  // blocks | records << 16 inside the subsequence
-    uint32_t *s_mark = s_cnt + T;                // last round in which the slot was a work item
-    uint32_t *s_lp = s_mark + T;                 // work list: start bit position,
-    uint32_t *s_lst = s_lp + T;                  //   z | m << 6 | slot << 9
-    uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_lst + T); // ... end state z | m << 8
+    uint32_t *s_mk0 = s_cnt + T;                 // restart streams: index of the first marker past the slot's first bit
+    uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_mk0 + T); // ... end state z | m << 8
     uint16_t *s_uzm = s_ezm + T;                               // ... start state z | m << 8
-    uint32_t *s_mk0 = s_lst + 2 * T;             // restart streams: index of the first marker past the slot's first bit
-    uint32_t *s_wc = s_lst + 3 * T;              // work items per wave
+    uint8_t *s_mark = reinterpret_cast<uint8_t *>(s_mk0 + 2 * T); // last round (+1, <= 96) in which the slot was a work item
+    uint32_t *s_wc = s_mk0 + 2 * T + T / 4;      // work items per wave
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 16);
     uint32_t *s_rows = s_wc + 32;
+    // The work list — start bit position; z | m << 6 | slot << 9 — and the scratch of the run rule live in the first 2 T words of
+    // the staging windows: the list is read into registers, behind a barrier, before a round's first window is staged.  (With
+    // arrays of their own and a 32-bit s_mark the workgroup took 86 KB: one per CU.  81 KB: two, which is what batches of small
+    // images, one workgroup per image at least, are short of.)
+    uint32_t *s_lp = s_rows;
+    uint32_t *s_lst = s_rows + T;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     RowEnv E;
@@ -683,7 +687,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     };
     stamp(nsub);
     uint32_t ndec_total = 0, nphase_items = 0;
-    s_mark[tid] = 0u;
+    s_mark[tid] = 0;
 
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
@@ -885,24 +889,26 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         }
         // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's first slots with a new state would go
         // on through the whole run, one lane, window after window — the run takes the new records in the next round instead.
-        if (elig) s_mark[tid] = rounds + 1u;
+        if (elig) s_mark[tid] = (uint8_t)(rounds + 1u);
         if (dirty) {
             const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             s_lp[t] = wp;
             s_lst[t] = (wzm & 63u) | ((wzm >> 8) << 6) | (tid << 9);
             s_up[tid] = wp;
             s_uzm[tid] = (uint16_t)wzm;
-            s_mark[tid] = rounds + 1u;
+            s_mark[tid] = (uint8_t)(rounds + 1u);
         }
         __syncthreads();
         stamp(0x100 + n);
         // the round's items: every wave walks its own, window by window
         uint32_t steps_done = 0;
+        bool live = tid < n;
+        const uint32_t st = live ? s_lst[tid] : 0u;
+        uint32_t p = live ? s_lp[tid] : 0u;
+        __syncthreads(); // the list is in registers: its place is the staging windows' again
         if (wv * 64u < n) { // waves without work go straight to the barrier
-            bool live = tid < n;
-            const uint32_t st = live ? s_lst[tid] : 0u;
             uint32_t slot = st >> 9, ph = 0u;
-            uint32_t p = live ? s_lp[tid] : 0u, z = st & 63u, m = (st >> 6) & 7u;
+            uint32_t z = st & 63u, m = (st >> 6) & 7u;
             uint32_t cn = 0u, co = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
             uint32_t wmk = live ? s_mk0[slot] : 0u; // the walk's marker scan: never behind the state's position, which only grows
             for (uint32_t step = 0; __any(live) && step < 65536u; step++) {
@@ -932,7 +938,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                         const uint32_t nx = slot + 1u;
                         live = nx < T && row0 + nx < lim && s_mark[nx] != rounds + 1u; // walk on: nobody else works on nx this round
                         if (live) {
-                            s_mark[nx] = rounds + 1u;
+                            s_mark[nx] = (uint8_t)(rounds + 1u);
                             s_up[nx] = p;
                             s_uzm[nx] = (uint16_t)(z | (m << 8));
                             slot = nx;

@@ -83,7 +83,7 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         assert o.nwritewg <= o.wgsum_entries             # k_repair_totals writes wgsum[wg * (T * nph / WW) + h] only below nwritewg (guarded)
         assert WW % nph == 0 and T_ % (WW // nph) == 0   # a final-pass workgroup covers whole subsequences, a repair workgroup whole final-pass workgroups
         # --- LDS of the entropy kernels: tables, state arrays, then one window of phase_words + 2 words per lane
-        assert o.lds_state_word_sync >= o.lds_state_word and o.lds_bytes_sync >= (o.lds_state_word_sync + 8 * T_ + 32 + (T_ // 64) * (o.phase_words + 2) * 64) * 4
+        assert o.lds_state_word_sync >= o.lds_state_word and o.lds_bytes_sync >= (o.lds_state_word_sync + 5 * T_ + T_ // 4 + 32 + (T_ // 64) * (o.phase_words + 2) * 64) * 4 and (T_ // 64) * (o.phase_words + 2) * 64 >= 2 * T_  # the work list lives in the staging windows
         assert o.lds_bytes_write >= (o.lds_state_word + 64 + 8 * WW + (wps + 2) * (WW // nph + 1)) * 4   # k_write: scratch + the lanes' record bursts (HJD_REC_RUN words each) + the workgroup's rows, all of their words
         assert o.lds_bytes_sync <= 160 * 1024 and o.lds_bytes_write <= 160 * 1024
         # --- checkpoints: canonical entry (ph, i) of the (only) image at ph * nsub_cap + i; k_sync workgroup w's scratch
