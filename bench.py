@@ -386,7 +386,7 @@ def main():
         ovl = dict(stages_ovl)
         iso = dict(stages_iso)
         kernel_of = {"unstuff": "k_unstuff_count+k_unstuff_write", "huff_sync": "k_sync", "huff_repair": "k_repair_totals",
-                     "scan": "k_scan", "huff_write": "k_write", "dc_scan": "k_dcsum+k_dcapply", "idct_color": "k_idct_color"}
+                     "huff_write": "k_write", "dc_scan": "k_dcsum+k_dcapply", "idct_color": "k_idct_color"}
         images_per_launch = len(jpgs) // ns
         # The dominant kernel and its duration come from INSIDE the timed region (hipEvents on the stream each launch goes
         # to; other streams' kernels run beside it) — the same quantity `rocprofv3 --kernel-trace --stats` of this command

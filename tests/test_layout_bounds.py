@@ -79,7 +79,7 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         assert K < T_ and o.nsyncwg * Q >= nsub          # k_sync: workgroup w owns [w*Q, (w+1)*Q)
         assert o.nrepwg * T_ >= nsub                     # k_repair
         nph = wps // o.phase_words
-        assert o.nwritewg * WW >= nsub * nph             # k_write, k_scan: one lane per staging window
+        assert o.nwritewg * WW >= nsub * nph             # k_write: one lane per staging window
         assert o.nwritewg <= o.wgsum_entries             # k_repair_totals writes wgsum[wg * (T * nph / WW) + h] only below nwritewg (guarded)
         assert WW % nph == 0 and T_ % (WW // nph) == 0   # a final-pass workgroup covers whole subsequences, a repair workgroup whole final-pass workgroups
         # --- LDS of the entropy kernels: tables, state arrays, then one window of phase_words + 2 words per lane
