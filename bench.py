@@ -107,6 +107,12 @@ def cpu_baseline(distinct, w, h):
                           "sample": "%d images, one process per core (%d usable of %d)" % (len(work), cores, os.cpu_count() or 0)}}
 
 
+def PG_TIMEOUT_S():
+    """Timeout of the process group (rendezvous and every collective), seconds: a rank that is missing makes the job
+    fail after this long, not after torch's 10-30 min default."""
+    return float(os.environ.get("HJD_BENCH_PG_TIMEOUT", "120"))
+
+
 def spawn_ranks(n, argv):
     """Parent of a self-launched multi-rank run.  Touches no GPU API (the children must be able to
     initialise their devices freshly); returns the exit code for the whole job.  ALL children are polled: as soon
@@ -161,22 +167,28 @@ def dry_rank(args, rank, world):
     a builder run on a card (BASELINE config 4: 8 ranks).  Decodes nothing and says so: "dry": true, value from a made-up clock."""
     import torch.distributed as dist
     shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
+    backend, seen = "none", 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")
+        backend = shard.fail_fast("init_process_group", shard.init_group, "gloo", None, PG_TIMEOUT_S())
+        seen = shard.fail_fast("rank count", shard.ranks_seen, "cpu")
     n_global = world * args.batch
     parts = shard.partition([args.width * args.height] * n_global, world)
     assert sorted(sum(parts, [])) == list(range(n_global))
     mine = parts[rank]
+    if os.environ.get("HJD_BENCH_HANG_RANK") == str(rank):  # test knob: this rank never reaches the barrier
+        time.sleep(3600)
     if world > 1:
-        dist.barrier()
-    dt, px = shard.agree(0.001 * (rank + 1) * args.steps, float(len(mine) * args.width * args.height), device="cpu")
+        shard.fail_fast("barrier", dist.barrier)
+    dt, px = shard.fail_fast("clock agreement", shard.agree, 0.001 * (rank + 1) * args.steps,
+                             float(len(mine) * args.width * args.height), device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)", "dry": True, "n_gpus": world, "steps": args.steps,
+                          "backend": backend, "ranks_seen": seen,
                           "value": round(px * args.steps / dt / 1e6, 1), "ms_per_step": round(dt / args.steps * 1e3, 4),
                           "config": {"images_per_gpu": len(mine), "global_images": n_global}}), flush=True)
     if world > 1:
-        dist.barrier()
+        shard.fail_fast("barrier", dist.barrier)
         dist.destroy_process_group()
 
 
@@ -225,22 +237,21 @@ def main():
     if "HJD_BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["HJD_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:  # the data path needs no collective: agreeing on the clock works over gloo too
-                print("bench: RCCL init failed (%s); using gloo for the barrier/clock agreement" % e, file=sys.stderr)
-                backend = "gloo"
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=backend)
-        assert dist.get_world_size() == args.gpus
-
     import hjdtools as T
     hjd = importlib.import_module("hls-jpeg-decoder_amd")
     shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
+    seen = 1
+    if world > 1:
+        # explicit timeout; RCCL comes up eagerly on this rank's device (a rank that cannot reach its peers fails HERE);
+        # the backend really in use and the number of ranks that answered an all-reduce of ones go into the JSON line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = shard.fail_fast("init_process_group", shard.init_group, backend, local_rank, PG_TIMEOUT_S())
+        assert dist.get_world_size() == args.gpus
+        seen = shard.fail_fast("rank count", shard.ranks_seen, "cuda" if backend == "nccl" else "cpu")
+        if seen != world:
+            raise SystemExit("bench: %d ranks answered, %d expected" % (seen, world))
+    else:
+        backend = "none"
 
     # ONE global batch of world x batch images, image g = synthetic source number g mod (distinct x world);
     # every rank computes the same partition (cost = pixels) and decodes its own shard.
@@ -288,8 +299,11 @@ def main():
     streams = [ts.cuda_stream for ts in tstreams]
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if world > 1:  # a failed barrier ends this rank (non-zero) at once; the launcher ends the others
+            if backend == "nccl":
+                shard.fail_fast("barrier", dist.barrier, device_ids=[local_rank])
+            else:
+                shard.fail_fast("barrier", dist.barrier)
         torch.cuda.synchronize()
 
     def step():
@@ -377,8 +391,9 @@ def main():
     if rank == 0 and not args.no_end_to_end and hasattr(dec, "decode_host_pipelined_bench"):
         e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
 
-    dt, total_pixels = shard.agree(dt, pixels, device="cuda" if backend == "nccl" else "cpu")  # MAX of time, SUM of pixels
-    spread_dt = [shard.agree(x, 0.0, device="cuda" if backend == "nccl" else "cpu")[0] for x in spread_dt]
+    adev = "cuda" if backend == "nccl" else "cpu"
+    dt, total_pixels = shard.fail_fast("clock agreement", shard.agree, dt, pixels, device=adev)  # MAX of time, SUM of pixels
+    spread_dt = [shard.fail_fast("clock agreement", shard.agree, x, 0.0, device=adev)[0] for x in spread_dt]
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -393,7 +408,8 @@ def main():
         # averages (profiles/r03_kernel_stats.csv).  The isolated replay (same launches, alone on the GPU) is a named extra.
         timing = "overlapped" if stages_ovl else "isolated"
         src = stages_ovl if stages_ovl else stages_iso
-        dom = max(src, key=lambda x: x[1]) if src else ("none", 0.0)
+        # "sync_wait" is no kernel: the interval a run waits for another run's synchronisation (hjd_decoder::sync_conc)
+        dom = max((x for x in src if x[0] != "sync_wait"), key=lambda x: x[1]) if src else ("none", 0.0)
         src_hash = T.kernel_src_hash()
         dropped = []
 
@@ -430,6 +446,8 @@ def main():
         valu_step = 0
         valu_nominal_cycles_step = 0.0
         for name, ms in (stages_iso or stages_ovl):
+            if name == "sync_wait":
+                continue
             t_ovl = ovl.get(name)
             tr = own_traffic(name)
             ent = {"kernel": kernel_of.get(name, name), "ms_isolated": round(iso[name], 4) if name in iso else None,
@@ -478,6 +496,8 @@ def main():
             "value": round(value, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
+            "backend": backend,        # process group the ranks met over: "nccl" (= RCCL), "gloo", or "none" for one rank
+            "ranks_seen": seen,        # an all-reduce of ones over that group
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),

@@ -32,7 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <atomic>
+#include <mutex>
 
 #include "hjd_device.h"
 #include "hjd_kernels.h"
@@ -1191,17 +1191,18 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 // (round 2 paid a hipFuncSetAttribute per launch, 36 per bench step).  `which` = 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_write.
 static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
 {
-    static std::atomic<uint32_t> granted[4][16];
+    // hipFuncSetAttribute is last-writer-wins, so the check, the call and the record of what was granted are ONE critical
+    // section: two host threads launching the same kernel for the first time with different sizes (decoders with different
+    // subsequence sizes or staging windows) must not leave the attribute below what the table says was granted.
+    static std::mutex mu;
+    static uint32_t granted[4][16];
     if (bytes <= 32768) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
-    const bool cached = dev < 16;
-    if (cached && granted[which][dev].load(std::memory_order_relaxed) >= bytes) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 16 && granted[which][dev] >= bytes) return 0;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
-    if (cached) { // keep the maximum: concurrent callers may raise it in either order
-        uint32_t cur = granted[which][dev].load(std::memory_order_relaxed);
-        while (cur < bytes && !granted[which][dev].compare_exchange_weak(cur, bytes)) {}
-    }
+    if (dev < 16) granted[which][dev] = bytes;
     return 0;
 }
 

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <thread>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/hjd.h"
@@ -43,26 +44,49 @@ static int host_threads()
     return n;
 }
 
+// Returns false when f threw (the callers turn that into HJD_ERR_INTERNAL: no exception leaves an extern "C" entry point).
 template <class F>
-static void parallel_for(int n, size_t work_bytes, F f)
+static bool parallel_for(int n, size_t work_bytes, F f)
 {
     int nt = host_threads();
     if (work_bytes < ((size_t)4 << 20) || n < 2 * nt) nt = 1;
     if (nt <= 1) {
-        for (int i = 0; i < n; i++) f(i);
-        return;
+        try {
+            for (int i = 0; i < n; i++) f(i);
+        } catch (...) {
+            return false;
+        }
+        return true;
     }
+    // The calling thread is worker 0; nt - 1 threads are spawned beside it.  A thread that cannot be created (EAGAIN under the
+    // pool's per-card process / thread limits: 8 ranks x 8 threads) is simply not there — the others, the caller at least,
+    // work the indices off — and an exception out of f is carried back to the caller after every started thread has been
+    // joined: nothing may unwind past a joinable std::thread (std::terminate in a process that holds the GPU).
     std::vector<std::thread> th;
     std::atomic<int> next{0};
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([&] {
+    std::atomic<bool> err{false};
+    auto worker = [&] {
+        try {
             for (;;) {
                 const int i0 = next.fetch_add(16);
                 if (i0 >= n) return;
                 for (int i = i0; i < n && i < i0 + 16; i++) f(i);
             }
-        });
+        } catch (...) {
+            err.store(true);
+            next.store(n); // the other workers stop at their next fetch
+        }
+    };
+    try {
+        th.reserve((size_t)nt - 1);
+        for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    } catch (const std::system_error &) {
+        // fewer helpers than asked for
+    } catch (const std::bad_alloc &) {
+    }
+    worker();
     for (auto &t : th) t.join();
+    return !err.load();
 }
 
 static const uint8_t kZzToSlot[64] = HJD_ZZ_TO_SLOT;
@@ -755,14 +779,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             b->h_stage_cap = total + total / 16;
         }
         uint8_t *h = b->h_stage;
-        parallel_for(b->n, raw_cur, [&](int i) {
-            const int di = b->dev_index[i];
-            if (di < 0) return;
-            const HjdImage &im = b->img[di];
-            memcpy(h + im.raw_off, parsed[i].stream, parsed[i].stream_len);
-            const size_t slab = align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
-            memset(h + im.raw_off + parsed[i].stream_len, 0, slab - parsed[i].stream_len); // the kernels read whole 16-byte pieces
-        });
+        if (!parallel_for(b->n, raw_cur, [&](int i) {
+                const int di = b->dev_index[i];
+                if (di < 0) return;
+                const HjdImage &im = b->img[di];
+                memcpy(h + im.raw_off, parsed[i].stream, parsed[i].stream_len);
+                const size_t slab = align_up((size_t)im.nchunks * HJD_UNSTUFF_CHUNK + 16, 256);
+                memset(h + im.raw_off + parsed[i].stream_len, 0, slab - parsed[i].stream_len); // the kernels read whole 16-byte pieces
+            }))
+            return HJD_ERR_INTERNAL;
         memcpy(h + o_img, b->img.data(), sizeof(HjdImage) * b->nimg);
         memcpy(h + o_tab, tabs.data(), sizeof(HjdTableSet) * tabs.size());
         memcpy(h + o_map, maps.data(), sizeof(uint32_t) * maps.size());
@@ -990,7 +1015,8 @@ extern "C" int hjd_batch_reset(hjd_batch *b, int n, const uint8_t *const *jpg, c
     const int pf = b->dec->conformant ? HJD_PARSE_CONFORMANT : 0;
     size_t total = 0;
     for (int i = 0; i < n; i++) total += jpg[i] ? jpg_len[i] : 0;
-    parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; });
+    if (!parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; }))
+        return HJD_ERR_INTERNAL;
     return batch_reset_parsed(b, n, parsed, pst, out_format, status, (hipStream_t)hip_stream, false);
 }
 
@@ -1006,7 +1032,10 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
     const int pf = d->conformant ? HJD_PARSE_CONFORMANT : 0;
     size_t total = 0;
     for (int i = 0; i < n; i++) total += jpg[i] ? jpg_len[i] : 0;
-    parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; });
+    if (!parallel_for(n, total, [&](int i) { pst[i] = jpg[i] ? hjd_parse_header_ex(jpg[i], jpg_len[i], &parsed[i], pf) : HJD_ERR_ARG; })) {
+        hjd_set_last_status(HJD_ERR_INTERNAL);
+        return nullptr;
+    }
     return batch_from_parsed(d, n, parsed, pst, out_format, status);
 }
 
@@ -1043,6 +1072,11 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         // staggered ranges (batch_enqueue): this range's synchronisation — a latency chain that leaves most issue slots
         // empty — starts when the previous range has finished its own, so that it runs beside that range's final pass and
         // IDCT instead of beside three other synchronisation kernels
+        // The waits below belong to no kernel: with a limit of two synchronisation kernels at a time and four caller streams a
+        // run spends longer waiting for another run's k_sync than in its own unstuff stage.  They get a stage of their own
+        // ("sync_wait"), so that the unstuff stage's interval is its kernels' and nothing else.
+        const bool waits = wait_before_sync || (b->dec->sync_conc > 0 && !b->dry);
+        if (waits && (rc = mark("sync_wait"))) return rc;
         if (wait_before_sync && hipStreamWaitEvent(s, wait_before_sync, 0) != hipSuccess) return HJD_ERR_INTERNAL;
         hipEvent_t conc_record = nullptr;
         if (b->dec->sync_conc > 0 && !b->dry) { // front-end concurrency limit: see hjd_decoder::sync_conc
@@ -1096,6 +1130,11 @@ static int emulation_enqueue(hjd_batch *b, hipStream_t s)
     }
     HIPCHK(hipEventRecord(b->seq_done, b->seq_stream));
     b->seq_pending = true;
+    // The caller's stream joins the side stream: whatever the caller enqueues after hjd_batch_run (its own kernels on the
+    // outputs, hjd_decode_batch_host's download) is ordered after the second back-end launch that rewrites the images the
+    // emulation decoded.  Free for batches without DRI (nothing is enqueued here at all); for clean restart streams the two
+    // launches return at once.
+    HIPCHK(hipStreamWaitEvent(s, b->seq_done, 0));
     return HJD_OK;
 }
 

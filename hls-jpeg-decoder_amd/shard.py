@@ -22,6 +22,56 @@ def partition(costs, world_size):
     return shards
 
 
+def init_group(backend, local_rank=None, timeout_s=120.0):
+    """Joins the process group the launcher's environment describes (RANK / WORLD_SIZE / MASTER_*) with an EXPLICIT
+    timeout, and returns the backend that is really in use.  "nccl" (= RCCL on ROCm) is initialised eagerly on the rank's
+    own device, so that a rank that cannot reach its peers fails here, within the timeout, and not inside the first
+    barrier of a timed region; if RCCL cannot be brought up at all the group falls back to gloo — the data path has no
+    collective, only the clock agreement needs a group — and the caller's JSON line says which one it was."""
+    import datetime
+    import sys
+    import torch
+    import torch.distributed as dist
+    to = datetime.timedelta(seconds=float(timeout_s))
+    if backend == "nccl":
+        try:
+            dist.init_process_group(backend="nccl", timeout=to, device_id=torch.device("cuda", int(local_rank or 0)))
+            return "nccl"
+        except Exception as e:
+            print("shard: RCCL init failed (%s); using gloo for the barrier / clock agreement" % e, file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+    dist.init_process_group(backend=backend, timeout=to)
+    return backend
+
+
+def ranks_seen(device=None):
+    """How many ranks actually take part: an all-reduce of ones.  1 without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def fail_fast(what, fn, *args, **kw):
+    """Runs a collective; a failure (a peer that is gone, a timeout) ends THIS process with a non-zero code at once —
+    no clean-up that could block on the broken group — so that the launcher sees the job fail within seconds of the
+    group's timeout instead of hanging in teardown."""
+    import os
+    import sys
+    try:
+        return fn(*args, **kw)
+    except BaseException as e:  # noqa: BLE001 - anything a backend throws, SystemExit of a watchdog included
+        print("shard: %s failed: %s: %s" % (what, type(e).__name__, e), file=sys.stderr)
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(3)
+
+
 def agree(elapsed_s, units, device=None):
     """(max over ranks of elapsed_s, sum over ranks of units).  No-op without a process group."""
     import torch

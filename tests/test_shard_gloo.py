@@ -115,6 +115,7 @@ def test_eight_rank_rehearsal_of_config4_plumbing():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["dry"] is True and line["n_gpus"] == 8
+    assert line["backend"] == "gloo" and line["ranks_seen"] == 8  # the line says how many ranks met, and over what
     assert line["config"] == {"images_per_gpu": 1024, "global_images": 8192}
     # SUM over the 8 ranks of their shards' pixels, MAX over the ranks of their (made-up) clocks: rank 7's 8 ms per step
     assert abs(line["ms_per_step"] - 8.0) < 1e-6
@@ -138,3 +139,22 @@ def test_a_dead_rank_ends_the_job_within_seconds():
         assert "ranks failed" in r.stderr and "told to fail" in r.stderr
         assert "n_gpus" not in r.stdout
         assert dt < 60, dt  # eight interpreter + torch start-ups, then seconds
+
+
+def test_a_rank_that_never_reaches_the_barrier_ends_the_job_within_the_group_timeout():
+    """All 4 ranks join the group, then one hangs (HJD_BENCH_HANG_RANK) and never enters the barrier.  The process group
+    was created with an explicit timeout (HJD_BENCH_PG_TIMEOUT, here 8 s): the waiting ranks' barrier fails, each exits
+    non-zero at once (shard.fail_fast), the parent terminates the hanging rank — a non-zero exit within seconds, no line."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=_bench_env(HJD_BENCH_DRY="1", HJD_BENCH_HANG_RANK="2", HJD_BENCH_PG_TIMEOUT="8"),
+                       capture_output=True, text=True, timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and "barrier failed" in r.stderr
+    assert "n_gpus" not in r.stdout
+    assert dt < 90, dt
