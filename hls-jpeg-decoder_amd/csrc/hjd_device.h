@@ -31,8 +31,14 @@
 #define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
 #ifndef HJD_SYNC_WG
-#define HJD_SYNC_WG 512        // threads (= subsequences incl. warm-up) per synchronisation workgroup
+#define HJD_SYNC_WG 512        // subsequences (slots, incl. warm-up) per synchronisation workgroup
 #endif
+#ifndef HJD_SYNC_C
+#define HJD_SYNC_C 1           // subsequences every lane of a synchronisation workgroup decodes side by side (independent chains in
+                               // one loop body: one chain's table look-up hides behind the other's arithmetic); the workgroup
+                               // has HJD_SYNC_WG / HJD_SYNC_C lanes
+#endif
+#define HJD_SYNC_THREADS (HJD_SYNC_WG / HJD_SYNC_C)
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
@@ -63,11 +69,11 @@ struct HjdTableSet {
     uint16_t sec[HJD_MAX_SEC][1 << HJD_SEC_BITS];
     // The same tables in the form the synchronisation pass wants (it needs no values): bits 0-4 code length + value bits
     // (0 = long code, as above), bits 5-11 zig-zag advance, bits 14-15 = AC records the step produces.
-    // Two entries per index: [0] the symbol at the head of the window; [1] that symbol AND the next one as a single
-    // step (lengths, advances and records added up) wherever the next code lies wholly inside the HJD_LUT_BITS window
-    // and the first symbol is neither an end-of-block nor a long code — else a copy of [0].  The decoder takes [1]
-    // while the first symbol cannot end the block (z < 48: an AC advance is at most 16) and the second symbol still
-    // starts inside the subsequence.  On the q85 bench content 38 % of the look-ups go away.
+    // Two entries per index, read as ONE 32-bit word: [0] (low half) the symbol at the head of the window; [1] that symbol AND
+    // the next one as a single step (lengths, advances and records added up) wherever the next code lies wholly inside the
+    // HJD_LUT_BITS window and the first symbol is neither an end-of-block nor a long code — else a copy of [0].  The decoder
+    // takes [1] while the first symbol cannot end the block (z < 48: an AC advance is at most 16) and the second symbol still
+    // starts inside the staging window.  On the q85 bench content 38 % of the look-ups go away.
     uint16_t lut_s[HJD_SLOTS][HJD_LUT_SIZE][2];
     uint16_t sec_s[HJD_MAX_SEC][1 << HJD_SEC_BITS];
 };

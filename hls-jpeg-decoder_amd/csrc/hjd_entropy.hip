@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "hjd_device.h"
 #include "hjd_kernels.h"
@@ -41,7 +42,7 @@
 __constant__ uint8_t c_zz_to_slot[64] = HJD_ZZ_TO_SLOT;
 
 struct EntropyLds {
-    const uint16_t *lut; // [nlut][HJD_LUT_SIZE]
+    const uint16_t *lut; // [nlut][HJD_LUT_SIZE]  (synchronisation form: [nlut][HJD_LUT_SIZE][2], see HjdTableSet::lut_s)
     const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
     const uint2 *mt;     // [nb] block-in-MCU m -> (byte offsets DC | AC << 16 of its tables, next m): the block-end step is
                          // taken by some lane of a wave in nearly every iteration, so it is two LDS reads instead of nine VALU
@@ -61,7 +62,7 @@ __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t 
 }
 
 template <bool SYNC_FORM>
-__device__ __forceinline__ void load_tables(const HjdTableSet *ts, uint16_t *s_lut, uint16_t *s_sec)
+__device__ __forceinline__ void load_tables(const HjdTableSet *ts, void *s_lut, void *s_sec)
 {
     const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * (SYNC_FORM ? 4 : 2) / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->lut_s[0][0][0] : &ts->lut[0][0]);
@@ -196,8 +197,8 @@ __device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *_
         // [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The pair is taken while the first
         // symbol cannot end the block (an AC advance is at most 16) and the second still starts inside the window (a step
         // is at most 31 bits): the states passed on are then exactly those of the symbol-by-symbol walk of the final pass.
-        const uint16_t *ep = reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
-        const uint32_t e1 = ep[0], e2 = ep[1];
+        const uint32_t ep = *reinterpret_cast<const uint32_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
+        const uint32_t e1 = ep & 0xFFFFu, e2 = ep >> 16;
         // restart streams: only while the next marker is more than a step (31 bits) plus the 8 bits of the rules' look-ahead
         // away, so that no marker rule could have fired at the boundary the pair steps over
         uint32_t e = (z < 48u && p < pair_lim && (!RESTART || p + 40u < mnext)) ? e2 : e1;
@@ -465,109 +466,342 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
     }
 }
 
-// One subsequence (row i of the image), window by window: stage phase_words + 2 words of the row into
-// the lane's LDS column, decode until the window's end, stage the next.  `active` lanes only.
-struct RowEnv {
-    const HjdParams *P;
-    const HjdImage *im;
-    EntropyLds L;
-    uint32_t tabY, tabCb, tabCr;
-    const uint32_t *wbase;  // the image's transposed stream
-    uint32_t *s_col;        // this lane's column of its wave's staging rows (word k at [k*64])
-    uint32_t total_bits;
-    uint32_t nmark;         // restart mode: markers found
-};
-
-template <class AfterPhase>
-__device__ __forceinline__ void decode_row_sync(const RowEnv &E, bool active, uint32_t i, uint32_t &p, uint32_t &z, uint32_t &m,
-                                                uint32_t &nblk, uint32_t &nrec, uint32_t &mk0, AfterPhase after_phase)
-{
-    const HjdParams &P = *E.P;
-    const HjdImage &im = *E.im;
-    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
-    const uint32_t sp = i * S;
-    const uint32_t end = min(sp + S, E.total_bits);
-    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
-    if (im.restart && active) {
-        rc.nmark = E.nmark;
-        uint32_t lo = 0, hi = rc.nmark; // first marker past the start of this row
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rc.mpos[mid] <= sp) lo = mid + 1;
-            else hi = mid;
-        }
-        rc.mk = lo;
-        mk0 = lo; // kept per subsequence (sync_body): refinement walks, repair launches and k_write start their marker scan here
-    }
-    const uint32_t nph = (1u << lw) / WPP;
-    const uint32_t *src0 = row_base(E.wbase, i, lw);
-    for (uint32_t ph = 0; ph < nph; ph++) {
-        const uint32_t bit0 = sp + ph * WPP * 32u;
-        const uint32_t pend = min(bit0 + WPP * 32u, end);
-        const bool go = active && p < pend;
-        // Two-symbol steps of the synchronisation pass stop 32 bits short of the WINDOW's end: the state a decode holds at a
-        // window's end is then the first symbol boundary at or past it whatever pairs were taken before — the states passed
-        // on at a window's end are those of the symbol-by-symbol final pass, and two decodes that have fallen into step
-        // show the same state at every window's end (the checkpoint comparison of sync_body relies on that).
-        const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u;
-        if (go) {
-            const uint32_t *src = src0 + (size_t)ph * WPP * 64u;
-            for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-            if (im.restart) sync_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
-            else sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
-        }
-        after_phase(ph);
-    }
-}
-
-// The same for ONE staging window (phase ph) of subsequence i — synchronisation only: the work items of a refinement
-// round advance a window at a time, so that those whose state has fallen into step with the subsequence's previous decode
-// can drop out (sync_body).
-// `mk` (restart streams): in, an index at or before the first marker past p (0xFFFFFFFF: none known, search for it); out, the
-// scan's position after the window — a walk carries it from window to window (a binary search per window was 13 dependent
-// global loads for an image with 8000 markers).
-__device__ __forceinline__ void decode_phase_sync(const RowEnv &E, bool active, uint32_t i, uint32_t ph, uint32_t &p, uint32_t &z, uint32_t &m,
-                                                  uint32_t &nblk, uint32_t &nrec, uint32_t &mk)
-{
-    const HjdParams &P = *E.P;
-    const HjdImage &im = *E.im;
-    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
-    const uint32_t sp = i * S;
-    const uint32_t end = min(sp + S, E.total_bits);
-    const uint32_t bit0 = sp + ph * WPP * 32u;
-    const uint32_t pend = min(bit0 + WPP * 32u, end);
-    const uint32_t pair_lim = pend > 32u ? pend - 32u : 0u; // as in decode_row
-    if (!(active && p < pend)) return;
-    RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, 0u, im.conformant};
-    const uint32_t *src = row_base(E.wbase, i, lw) + (size_t)ph * WPP * 64u;
-    for (uint32_t k = 0; k < WPP + 2u; k++) E.s_col[k * 64u] = src[k * 64u];
-    if (im.restart) {
-        rc.nmark = E.nmark;
-        if (mk == 0xFFFFFFFFu) {
-            uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rc.mpos[mid] <= p) lo = mid + 1;
-                else hi = mid;
-            }
-            mk = lo;
-        }
-        rc.mk = min(mk, rc.nmark); // sync_span moves it past p
-        sync_span<true>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
-        mk = rc.mk;
-    } else {
-        sync_span<false>(E.L, E.s_col, bit0, E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p, z, m, pend, pair_lim, nblk, nrec, rc);
-    }
-}
-
 // ---- stage 1: synchronisation ----------------------------------------------------------------
+// A synchronisation workgroup holds HJD_SYNC_WG SLOTS = subsequences, HJD_SYNC_C per lane (slot (wv * C + c) * 64 + lane is chain c
+// of that lane, so that the 64 lanes of a wave hold 64 consecutive subsequences per chain: coalesced staging out of the
+// transposed stream).  What a lane does with a staging window is ONE loop (sync_window) in which nothing branches on a lane's data:
+// a chain that has reached the end of its window adds an entry of zero, the block-end work (next block's tables) is three
+// selects on values fetched unconditionally from a small LDS table, the table pair (this symbol alone / this symbol and the
+// next) is a select.  EXEC stays full, the loop is left when no lane of the wave has bits left, and the only branch inside is
+// the wave-uniform one to the second-level table (a code longer than HJD_LUT_BITS: 0.2 % of the symbols).
+//
+// What this loop costs is its instruction count: a wave issues ONE instruction of any kind every 4-5 cycles whatever the other
+// waves of its SIMD do (measured here: round 3's loop, ~80 instructions per step with its divergent regions, 500 cycles per step;
+// the compiler's version of the loop below 58 and 385; the hand-written one 42 and 330 with two waves per SIMD).  Several
+// chains per lane (HJD_SYNC_C = 2, built and measured this round: the look-ups of one chain in flight while the other's
+// arithmetic issues) shorten nothing: a workgroup then has half the waves, each with twice the instructions, and a SIMD with
+// one resident wave issues at half the rate of one with two — k_sync 0.47 ms against 0.32 for 16 images.  Waves, not chains
+// per wave, are what fills a SIMD; HJD_SYNC_C stays 1.
+//
+// Restart streams (images with DRI) keep the loop that knows the reference's marker rules (sync_span<true>).
+//
 // MODE 0: workgroup w of an image owns subsequences [w*Q, (w+1)*Q), Q = HJD_SYNC_WG - K, and additionally
 //         decodes the K subsequences before them as warm-up (their records belong to workgroup w-1).
 // MODE 1: repair / host re-synchronisation: HJD_SYNC_WG owned subsequences per workgroup, records reloaded,
 //         slot 0 takes its start from the previous workgroup's last record.  Returns at once (before the
 //         tables are even loaded) when every start state already equals its predecessor's end.
 // MODE 2: MODE 1 for the last repair launch, which also leaves the block / record totals of the final-pass
-//         workgroups it covers (k_scan's job when no repair launch is configured).
+//         workgroups it covers.
+
+struct SyncChain {
+    uint32_t p;        // bit position inside the staging window
+    uint32_t z;        // zig-zag index
+    uint32_t sh, hi, lo;
+    uint32_t nxa;      // LDS byte address of the next stream word (prefetched every step)
+    uint32_t dcb, acb; // LDS byte addresses of the current block's DC / AC table
+    uint32_t mi;       // LDS byte address of the block table's entry for the NEXT block of the MCU
+    uint32_t nblk;     // blocks completed in the window
+    uint32_t nrec;     // AC records in the window
+};
+
+// Block table of the synchronisation kernels, one uint4 per block-in-MCU index m: x / y = LDS byte addresses of its DC / AC table,
+// z = LDS byte address of the entry of m + 1 (cyclic), w = m - 1 (cyclic): what a chain whose `mi` points HERE is decoding.
+__device__ __forceinline__ void fill_block_table(uint4 *mt4, uint32_t lds_addr_of_mt4, uint32_t nb, uint32_t nby, uint32_t lut_addr,
+                                                 uint32_t tabY, uint32_t tabCb, uint32_t tabCr, uint32_t t)
+{
+    if (t < nb) {
+        const uint32_t pair = t < nby ? tabY : (t == nby ? tabCb : tabCr); // byte offsets DC | AC << 16
+        mt4[t] = make_uint4(lut_addr + (pair & 0xFFFFu), lut_addr + (pair >> 16), lds_addr_of_mt4 + (t + 1u == nb ? 0u : t + 1u) * 16u,
+                            t == 0u ? nb - 1u : t - 1u);
+    }
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; // generic -> LDS: the low 32 bits are the LDS byte address
+}
+// loads by LDS byte address (ds_read_b16 / b32 / b128)
+typedef uint32_t hjd_u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T lds_load(uint32_t a)
+{
+    return *(const __attribute__((address_space(3))) T *)(uintptr_t)a;
+}
+template <>
+__device__ __forceinline__ uint4 lds_load<uint4>(uint32_t a)
+{
+    const hjd_u32x4 v = *(const __attribute__((address_space(3))) hjd_u32x4 *)(uintptr_t)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// All chains of a lane through one staging window: until every chain's bit position has reached pend[c] (relative to the
+// window's first bit; 0 = the chain takes no part).  sec_addr: LDS byte address of the second-level tables.
+template <int NC>
+__device__ __forceinline__ void sync_window(SyncChain (&ch)[NC], const uint32_t (&pend)[NC], uint32_t sec_addr)
+{
+    uint32_t plim[NC]; // two-symbol steps stop 32 bits short of the window's end (see decode_windows)
+#pragma unroll
+    for (int c = 0; c < NC; c++) plim[c] = pend[c] > 32u ? pend[c] - 32u : 0u;
+    for (;;) {
+        unsigned long long actm[NC], anym = 0ull;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            actm[c] = __builtin_amdgcn_ballot_w64(ch[c].p < pend[c]);
+            anym |= actm[c];
+        }
+        if (anym == 0ull) break; // wave-uniform: EXEC stays full inside the loop
+        uint32_t win[NC], nw[NC], e[NC], w2[NC];
+        uint4 mt[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            win[c] = __builtin_amdgcn_alignbit(ch[c].hi, ch[c].lo, ch[c].sh);
+            const uint32_t tb = ch[c].z == 0u ? ch[c].dcb : ch[c].acb;
+            w2[c] = lds_load<uint32_t>(tb + ((win[c] >> (32 - HJD_LUT_BITS)) << 2)); // [0] | [1] << 16
+            nw[c] = lds_load<uint32_t>(ch[c].nxa);
+            mt[c] = lds_load<uint4>(ch[c].mi);
+        }
+        unsigned long long lngm = 0ull;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            // [0] this symbol, [1] this symbol and the next as one step.  The pair is taken while the first symbol cannot end the
+            // block (an AC advance is at most 16) and the second still starts inside the window (a step is at most 31 bits):
+            // the states passed on are then exactly those of the symbol-by-symbol walk of the final pass.
+            const bool pair = ch[c].z < 48u && ch[c].p < plim[c];
+            e[c] = pair ? w2[c] >> 16 : w2[c] & 0xFFFFu;
+            lngm |= actm[c] & __builtin_amdgcn_ballot_w64((e[c] & 31u) == 0u);
+        }
+        if (lngm != 0ull) {
+            // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
+            // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if ((e[c] & 31u) == 0u) {
+                    const uint32_t sub = e[c] >> 5;
+                    e[c] = sub ? lds_load<uint16_t>(sec_addr + (((sub - 1u) * HJD_SEC_SIZE + ((win[c] >> 16) & (HJD_SEC_SIZE - 1u))) << 1)) : 0u;
+                    if ((e[c] & 31u) == 0u) e[c] = 16u; // skip 16 bits: any progress will do, the final pass flags it
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint32_t ev = ch[c].p < pend[c] ? e[c] : 0u; // a chain at the end of its window stands still
+            const uint32_t tot = ev & 31u;
+            const uint32_t z2 = ch[c].z + __builtin_amdgcn_ubfe(ev, 5, 7);
+            const bool blk_end = z2 > 63u; // EOB or the last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
+            ch[c].nrec += ev >> 14;
+            ch[c].nblk += blk_end ? 1u : 0u;
+            ch[c].z = blk_end ? 0u : z2;
+            ch[c].dcb = blk_end ? mt[c].x : ch[c].dcb;
+            ch[c].acb = blk_end ? mt[c].y : ch[c].acb;
+            ch[c].mi = blk_end ? mt[c].z : ch[c].mi;
+            ch[c].p += tot;
+            const int sh2 = (int)ch[c].sh - (int)tot;
+            const bool roll = sh2 < 0;
+            ch[c].hi = roll ? ch[c].lo : ch[c].hi;
+            ch[c].lo = roll ? nw[c] : ch[c].lo;
+            ch[c].nxa += (uint32_t)sh2 & 0x100u; // + 256 bytes (the next word of the column) when the reader rolls: sh2 in -31..-1
+            ch[c].sh = (uint32_t)sh2 & 31u;
+        }
+    }
+}
+
+// One chain per lane (HJD_SYNC_C = 1, and every sparse refinement round): the same loop, instruction by instruction.  A wave issues
+// one instruction of any kind every 4-5 cycles whatever the other waves do, so the time of a walk is its instruction count:
+// the compiler's version of the loop above is 58 instructions per step (copies for its loop-carried values, nine for the
+// wave-uniform test of a 0.2 % case, separate shift / mask / add for what v_bfe_u32 and v_lshl_add_u32 do in one); this is 42.
+// v120-v123 receive the block table entry (ds_read_b128 needs four consecutive registers; inline assembly cannot name the
+// parts of a 128-bit operand).  All waits for the LDS reads issued here are inside: the compiler does not count them.
+template <>
+__device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_t (&pend)[1], uint32_t sec_addr)
+{
+    SyncChain &c = ch[0];
+    const uint32_t plim = pend[0] > 32u ? pend[0] - 32u : 0u;
+    const uint32_t secm = sec_addr - 2u * HJD_SEC_SIZE; // second-level table `sub` (1-based) starts at sec_addr + (sub - 1) * 2 * HJD_SEC_SIZE
+    uint32_t win, a, w, e, tot, t, nw;
+    unsigned long long act, pm, sv;
+    static_assert(HJD_LUT_BITS == 11 && HJD_SEC_BITS == 5, "field positions below");
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n\t"
+        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"       // lanes with bits left in the window
+        "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"   // the next 32 bits
+        "v_cmp_eq_u32_e32 vcc, 0, %[z]\n\t"
+        "s_cmp_eq_u64 %[act], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
+        "v_cndmask_b32_e32 %[t], %[acb], %[dcb], vcc\n\t"  // z == 0: DC table
+        "v_bfe_u32 %[a], %[win], 21, 11\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[t]\n\t"
+        "ds_read_b32 %[w], %[a]\n\t"                       // [0] | [1] << 16
+        "ds_read_b32 %[nw], %[nxa]\n\t"                    // next stream word
+        "ds_read_b128 v[120:123], %[mi]\n\t"               // next block's tables
+        "s_and_b64 vcc, vcc, %[pm]\n\t"                    // two symbols as one step
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_lshrrev_b32_e32 %[e], 16, %[w]\n\t"
+        "v_cndmask_b32_e32 %[e], %[w], %[e], vcc\n\t"      // bits 16.. of e are not looked at
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
+        "s_and_b64 %[pm], vcc, %[act]\n\t"                 // a live lane with a code longer than HJD_LUT_BITS?
+        "s_cbranch_scc0 2f\n\t"
+        "s_and_saveexec_b64 %[sv], %[pm]\n\t"              // second-level table on the next HJD_SEC_BITS bits
+        "v_bfe_u32 %[t], %[e], 5, 11\n\t"                  // 1 + table index, 0 = no code has this prefix
+        "v_bfe_u32 %[a], %[win], 16, 5\n\t"
+        "v_lshl_add_u32 %[a], %[t], 5, %[a]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 1, %[secm]\n\t"
+        "ds_read_u16 %[a], %[a]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 %[e], 0, %[a], vcc\n\t"
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
+        "v_cndmask_b32_e64 %[e], %[e], 16, vcc\n\t"        // no such code: skip 16 bits, the final pass flags it
+        "s_mov_b64 exec, %[sv]\n"
+        "2:\n\t"
+        "v_cndmask_b32_e64 %[e], 0, %[e], %[act]\n\t"      // a lane at the end of its window stands still
+        // three short chains, dealt out alternately: the reader (tot -> sh -> roll), the block (advance -> z -> end of block),
+        // the record count
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_bfe_u32 %[t], %[e], 5, 7\n\t"
+        "v_bfe_u32 %[a], %[e], 14, 2\n\t"
+        "v_sub_u32_e32 %[sh], %[sh], %[tot]\n\t"
+        "v_add_u32_e32 %[z], %[z], %[t]\n\t"
+        "v_add_u32_e32 %[nrec], %[nrec], %[a]\n\t"
+        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, %[sh]\n\t"               // the reader rolls on to the next word
+        "v_cmp_lt_u32_e64 %[pm], 63, %[z]\n\t"             // end of block
+        "v_and_b32_e32 %[t], 0x100, %[sh]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 %[hi], %[hi], %[lo], vcc\n\t"
+        "v_add_u32_e32 %[nxa], %[nxa], %[t]\n\t"
+        "v_cndmask_b32_e64 %[z], %[z], 0, %[pm]\n\t"
+        "v_cndmask_b32_e32 %[lo], %[lo], %[nw], vcc\n\t"
+        "v_cndmask_b32_e64 %[dcb], %[dcb], v120, %[pm]\n\t"
+        "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
+        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[pm]\n\t"
+        "v_cndmask_b32_e64 %[mi], %[mi], v122, %[pm]\n\t"
+        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[pm]\n\t"
+        "s_branch 1b\n"
+        "3:\n\t"
+        : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [dcb] "+v"(c.dcb),
+          [acb] "+v"(c.acb), [mi] "+v"(c.mi), [nblk] "+v"(c.nblk), [nrec] "+v"(c.nrec), [win] "=&v"(win), [a] "=&v"(a), [w] "=&v"(w),
+          [e] "=&v"(e), [tot] "=&v"(tot), [t] "=&v"(t), [nw] "=&v"(nw), [act] "=&s"(act), [pm] "=&s"(pm), [sv] "=&s"(sv)
+        : [pend] "v"(pend[0]), [plim] "v"(plim), [secm] "v"(secm)
+        : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
+}
+
+// What the decode of a window needs besides the chains' own state.
+struct RowEnv {
+    const HjdParams *P;
+    const HjdImage *im;
+    EntropyLds L;           // restart streams: the one-chain loop with the marker rules
+    uint32_t tabY, tabCb, tabCr;
+    const uint32_t *wbase;  // the image's transposed stream
+    uint32_t *s_stage;      // this WAVE's staging windows: chain c's column of this lane at s_stage[c * (WPP + 2) * 64 + lane + k * 64]
+    uint32_t mt4_addr;      // LDS byte address of the block table (fill_block_table)
+    uint32_t sec_addr;      // LDS byte address of the second-level tables
+    uint32_t total_bits;
+    uint32_t nmark;         // restart mode: markers found
+};
+
+// Staging window ph[c] of subsequence row[c], for every live chain c of this lane: stage WPP + 2 words of the row into the chain's
+// LDS column and decode from state (p, z, m) until the window's end; nblk / nrec = blocks completed / AC records inside the
+// window.  Chains with p already past the window's end (a marker jump) pass through unchanged.
+// Two-symbol steps stop 32 bits short of the WINDOW's end: the state a decode holds at a window's end is then the first symbol
+// boundary at or past it whatever pairs were taken before — the states passed on at a window's end are those of the
+// symbol-by-symbol final pass, and two decodes that have fallen into step show the same state at every window's end (the
+// checkpoint comparison of sync_body relies on that).
+// `mk` (restart streams): in, an index at or before the first marker past p (0xFFFFFFFF: none known, search for it); out, the
+// scan's position after the window — a walk carries it from window to window (a binary search per window was 13 dependent
+// global loads for an image with 8000 markers).
+template <int NC>
+__device__ __forceinline__ void decode_windows(const RowEnv &E, const bool (&live)[NC], const uint32_t (&row)[NC], const uint32_t (&ph)[NC],
+                                               uint32_t (&p)[NC], uint32_t (&z)[NC], uint32_t (&m)[NC], uint32_t (&nblk)[NC],
+                                               uint32_t (&nrec)[NC], uint32_t (&mk)[NC])
+{
+    const HjdParams &P = *E.P;
+    const HjdImage &im = *E.im;
+    const uint32_t S = P.subseq_bits, lw = P.log2_words, WPP = P.phase_words;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool go[NC];
+    uint32_t bit0[NC], pend[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t sp = row[c] * S;
+        const uint32_t end = min(sp + S, E.total_bits);
+        bit0[c] = sp + ph[c] * WPP * 32u;
+        pend[c] = min(bit0[c] + WPP * 32u, end);
+        go[c] = live[c] && p[c] < pend[c] && p[c] >= bit0[c];
+        nblk[c] = 0u;
+        nrec[c] = 0u;
+    }
+    // stage: all loads of all chains first (one global round trip), then the LDS stores
+    constexpr uint32_t MAXW = 66u;
+    (void)MAXW;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (go[c]) {
+            const uint32_t *src = row_base(E.wbase, row[c], lw) + (size_t)ph[c] * WPP * 64u;
+            uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
+            for (uint32_t k = 0; k < WPP + 2u; k++) col[k * 64u] = src[k * 64u];
+        }
+    }
+    if (im.restart) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (!go[c]) continue;
+            const uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
+            RestartCtx rc = {P.mpos + im.mark_off, E.nmark, 0u, im.ri_blocks, 0u, im.conformant};
+            if (mk[c] == 0xFFFFFFFFu) {
+                uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rc.mpos[mid] <= p[c]) lo = mid + 1;
+                    else hi = mid;
+                }
+                mk[c] = lo;
+            }
+            rc.mk = min(mk[c], rc.nmark); // sync_span moves it past p
+            const uint32_t pair_lim = pend[c] > 32u ? pend[c] - 32u : 0u;
+            sync_span<true>(E.L, col, bit0[c], E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p[c], z[c], m[c], pend[c], pair_lim, nblk[c], nrec[c], rc);
+            mk[c] = rc.mk;
+        }
+        return;
+    }
+    SyncChain ch[NC];
+    uint32_t prel[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t col = lds_addr(E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane);
+        const uint32_t rel = go[c] ? p[c] - bit0[c] : 0u;
+        const uint4 me = lds_load<uint4>(E.mt4_addr + (go[c] ? m[c] : 0u) * 16u);
+        ch[c].p = rel;
+        ch[c].z = go[c] ? z[c] : 0u;
+        ch[c].dcb = me.x;
+        ch[c].acb = me.y;
+        ch[c].mi = me.z;
+        ch[c].nblk = 0u;
+        ch[c].nrec = 0u;
+        // bit reader (see ReaderLds): hi, lo and sh = number of unconsumed bits of hi (0..31); window = alignbit(hi, lo, sh)
+        const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+        const uint32_t a = lds_load<uint32_t>(col + k0 * 256u), b = lds_load<uint32_t>(col + k0 * 256u + 256u);
+        ch[c].hi = a;
+        ch[c].lo = o0 ? b : a;
+        ch[c].nxa = col + (k0 + (o0 ? 2u : 1u)) * 256u;
+        ch[c].sh = (32u - o0) & 31u;
+        prel[c] = go[c] ? pend[c] - bit0[c] : 0u;
+    }
+    sync_window<NC>(ch, prel, E.sec_addr);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (go[c]) {
+            p[c] = bit0[c] + ch[c].p;
+            z[c] = ch[c].z;
+            m[c] = lds_load<uint4>(ch[c].mi).w;
+            nblk[c] = ch[c].nblk;
+            nrec[c] = ch[c].nrec;
+        }
+    }
+}
 
 // Blocks and records (each k_write lane's run rounded up to whole bursts) of one subsequence, from its checkpoints; a k_write
 // lane covers P.write_windows consecutive staging windows.  ckp(ph) = checkpoint word y of window ph.
@@ -587,18 +821,16 @@ __device__ __forceinline__ void subseq_totals(uint32_t nph, uint32_t ww, CkY cky
 }
 
 // Synchronisation, MODE 0 (k_sync).
-// Round 0: every lane first decodes the last P.lane_warm staging windows of the subsequence BEFORE its own from a guess (a
-//   code boundary at the window's first bit, z = 0, MCU phase 0) — after ~1 kbit such a decode has fallen into step with the true one
-//   in 70 % of the cases — and takes the state it crosses its own first bit with as its start state.  From there it decodes
-//   its own subsequence and leaves, next to the end state, a CHECKPOINT at the end of each staging window (P.ckpt: decoder
-//   state there + blocks / records decoded inside that window).
+// Round 0: every chain decodes its subsequence from a guess (a code boundary at its first bit, z = 0, MCU phase 0) and leaves,
+//   next to the end state, a CHECKPOINT at the end of each staging window (P.ckpt: decoder state there + blocks / records
+//   decoded inside that window).
 // Refinement rounds: a subsequence whose predecessor's end state differs from the start state it was decoded from becomes a
-//   WORK ITEM; the items are compacted onto the first lanes of the workgroup (__ballot + prefix over the waves) and every
-//   wave that holds items walks them window by window on its own (no barrier inside a round):
+//   WORK ITEM; the items are compacted (__ballot + prefix over the waves' chains) and dealt to the lanes — one per lane while
+//   they fit, HJD_SYNC_C per lane in the dense first round — and every wave that holds items walks them window by window on its
+//   own (no barrier inside a round):
 //   * an item whose state at a window's end EQUALS the checkpoint of the subsequence's previous decode has fallen into step
 //     with it — same bit position, same zig-zag index, same block-in-MCU — so the rest of that decode stands: its end state is
-//     kept, its totals are corrected by the difference over the windows walked, and the item is done.  (Round 2 of this
-//     project re-decoded whole subsequences: 2.11 decodes per subsequence, every sparse round a full subsequence of latency.)
+//     kept, its totals are corrected by the difference over the windows walked, and the item is done.
 //   * an item that reaches the end of its subsequence with a NEW end state walks on into the next subsequence unless that
 //     one is an item of this round itself: a state change runs down the chain inside one round instead of one
 //     subsequence per round.
@@ -607,8 +839,12 @@ template <int MODE>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    constexpr uint32_t T = HJD_SYNC_WG;
-    static_assert(T <= 1024, "work items carry their slot in 10 bits");
+    constexpr uint32_t NS = HJD_SYNC_WG;      // slots
+    constexpr uint32_t C = HJD_SYNC_C;        // chains per lane
+    constexpr uint32_t T = HJD_SYNC_THREADS;  // lanes
+    constexpr uint32_t NVW = NS / 64u;        // "virtual waves": 64 consecutive slots = chain c of wave wv, vw = wv * C + c
+    static_assert(NS <= 1024, "work items carry their slot in 10 bits");
+    static_assert(NS % (64 * C) == 0 && NVW <= 16, "whole waves; the per-virtual-wave scratch holds 16");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
@@ -616,51 +852,61 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     static_assert(HJD_SYNC_WG % HJD_WRITE_WG == 0, "a repair workgroup covers whole final-pass workgroups");
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
-    const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = T - K;
+    const uint32_t K = MODE == 0 ? P.sync_overlap : 0u, Q = NS - K;
     const uint32_t own0 = wg * Q, own1 = own0 + Q;
     const uint32_t row0 = own0 >= K ? own0 - K : 0u;
 
     const uint32_t S = P.subseq_bits;
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    const uint32_t i = row0 + tid;
     const uint32_t lim = min(own1, nsub); // subsequences [row0, lim) are this workgroup's slots
-    const bool valid = i < lim;
-    const bool owned = valid && i >= own0;
-    const uint32_t g = im.sub0 + i;
     const uint32_t nph = (S >> 5) / P.phase_words;
+    const uint32_t nwarm = own0 - row0;
 
-    // LDS: tables | per-slot state | work list | staging windows
-    uint16_t *s_lut = reinterpret_cast<uint16_t *>(s_dyn);
-    uint16_t *s_sec = reinterpret_cast<uint16_t *>(s_dyn + P.lds_sec_word_s);
+    // this lane's slots
+    uint32_t sl[C], row[C];
+    bool valid[C], owned[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        sl[c] = (wv * C + c) * 64u + lane;
+        row[c] = row0 + sl[c];
+        valid[c] = row[c] < lim;
+        owned[c] = valid[c] && row[c] >= own0;
+    }
+
+    // LDS: tables | per-slot state | scratch | block tables | staging windows
+    uint32_t *s_lut = s_dyn;
+    uint32_t *s_sec = s_dyn + P.lds_sec_word_s;
     uint32_t *s_ep = s_dyn + P.lds_state_word_s; // end state: bit position ...
-    uint32_t *s_up = s_ep + T;                   // the start state that end state was computed from: bit position ...
-    uint32_t *s_cnt = s_up + T;                  // blocks | records << 16 inside the subsequence
-    uint32_t *s_mk0 = s_cnt + T;                 // restart streams: index of the first marker past the slot's first bit
-    uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_mk0 + T); // ... end state z | m << 8
-    uint16_t *s_uzm = s_ezm + T;                               // ... start state z | m << 8
-    uint8_t *s_mark = reinterpret_cast<uint8_t *>(s_mk0 + 2 * T); // last round (+1, <= 96) in which the slot was a work item
-    uint32_t *s_wc = s_mk0 + 2 * T + T / 4;      // work items per wave
-    uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 16);
-    uint32_t *s_rows = s_wc + 32;
-    // The work list — start bit position; z | m << 6 | slot << 9 — and the scratch of the run rule live in the first 2 T words of
-    // the staging windows: the list is read into registers, behind a barrier, before a round's first window is staged.  (With
-    // arrays of their own and a 32-bit s_mark the workgroup took 86 KB: one per CU.  81 KB: two, which is what batches of small
-    // images, one workgroup per image at least, are short of.)
+    uint32_t *s_up = s_ep + NS;                  // the start state that end state was computed from: bit position ...
+    uint32_t *s_cnt = s_up + NS;                 // blocks | records << 16 inside the subsequence
+    uint32_t *s_mk0 = s_cnt + NS;                // restart streams: index of the first marker past the slot's first bit
+    uint16_t *s_ezm = reinterpret_cast<uint16_t *>(s_mk0 + NS); // ... end state z | m << 8
+    uint16_t *s_uzm = s_ezm + NS;                               // ... start state z | m << 8
+    uint8_t *s_mark = reinterpret_cast<uint8_t *>(s_mk0 + 2 * NS); // last round (+1, <= 96) in which the slot was a work item
+    uint32_t *s_wc = s_mk0 + 2 * NS + NS / 4;    // [0..15] work items per virtual wave, [16..31] the virtual waves' run heads, [32] scratch
+    uint2 *s_mt = reinterpret_cast<uint2 *>(s_wc + 48);  // 8 entries: block table of the one-chain loop (restart streams)
+    uint4 *s_mt4 = reinterpret_cast<uint4 *>(s_wc + 64); // 8 entries: block table of sync_window
+    uint32_t *s_rows = s_wc + 96;
+    // The work list — start bit position; z | m << 6 | slot << 9 — lives in the first 2 NS words of the staging windows: the
+    // list is read into registers, behind a barrier, before a round's first window is staged.
     uint32_t *s_lp = s_rows;
-    uint32_t *s_lst = s_rows + T;
+    uint32_t *s_lst = s_rows + NS;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     RowEnv E;
     E.P = &P;
     E.im = &im;
-    E.L = {s_lut, s_sec, s_mt};
+    E.L = {reinterpret_cast<const uint16_t *>(s_lut), reinterpret_cast<const uint16_t *>(s_sec), s_mt};
     E.tabY = table_pair(ts->slot_pack, 0, 4u);
     E.tabCb = table_pair(ts->slot_pack, 1, 4u);
     E.tabCr = table_pair(ts->slot_pack, 2, 4u);
     fill_mcu_table(s_mt, im.nb, im.nby, E.tabY, E.tabCb, E.tabCr);
+    E.mt4_addr = lds_addr(s_mt4);
+    E.sec_addr = lds_addr(s_sec);
+    fill_block_table(s_mt4, E.mt4_addr, im.nb, im.nby, lds_addr(s_lut), E.tabY, E.tabCb, E.tabCr, tid);
     E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
-    E.s_col = s_rows + wv * ((P.phase_words + 2u) * 64u) + lane;
+    E.s_stage = s_rows + wv * (C * (P.phase_words + 2u) * 64u);
     E.total_bits = total_bits;
     E.nmark = im.restart ? min(P.st[ii].nmarkers, im.mark_cap) : 0u;
 
@@ -669,13 +915,11 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     // scratch area private to the workgroup.
     uint2 *const ck_canon = P.ckpt + (size_t)im.sub0 * nph + row0;       // + window * nsub_cap + slot
     uint2 *const ck_scr = P.ckpt + P.ck_scratch + (size_t)bid * nph * K; // + window * K + slot        (MODE 0, slot < nwarm)
-    const uint32_t nwarm = own0 - row0;
     auto ck = [&](uint32_t ph, uint32_t slot) -> uint2 * {
         return slot >= nwarm ? ck_canon + (size_t)ph * im.nsub_cap + slot : ck_scr + ph * K + slot;
     };
 
-    const uint32_t sp = i * S;
-    uint32_t ext_p = sp, ext_zm = 0;      // start state offered to slot 0 from outside the workgroup
+    uint32_t ext_p = row0 * S, ext_zm = 0; // start state offered to slot 0 from outside the workgroup
     // HJD_SYNC_PROF (diagnostics, tools/sync_profile.py): shader-clock stamps of this workgroup's stages
     unsigned long long *dbg = (MODE == 0 && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
     uint32_t dbg_k = 0;
@@ -687,66 +931,91 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     };
     stamp(nsub);
     uint32_t ndec_total = 0, nphase_items = 0;
-    s_mark[tid] = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) s_mark[sl[c]] = 0;
 
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
         __syncthreads();
         stamp(0);
-        // round 0: warm-up inside the lane, then the lane's own subsequence
-        uint32_t p = sp, z = 0, m = 0, nblk = 0, nrec = 0, cb = 0, cr = 0;
-        const uint32_t nw = min(P.lane_warm, nph);
-        if (nw != 0u) {
-            const bool wu = valid && i > 0u;
-            p = sp - nw * P.phase_words * 32u;
-            uint32_t wmk = 0xFFFFFFFFu;
-            for (uint32_t ph = nph - nw; ph < nph; ph++) decode_phase_sync(E, wu, i - 1u, ph, p, z, m, nblk, nrec, wmk);
-            if (!wu || p < sp || p >= sp + 32u) { // no predecessor, or a marker jump took the walk elsewhere: the plain guess
-                p = sp;
-                z = 0;
-                m = 0;
+        // round 0: every chain its own subsequence, from the guess
+        uint32_t p[C], z[C], m[C], nblk[C], nrec[C], mk[C], tb[C], tr[C], phs[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            p[c] = row[c] * S;
+            z[c] = 0;
+            m[c] = 0;
+            tb[c] = tr[c] = 0;
+            mk[c] = 0xFFFFFFFFu;
+            s_up[sl[c]] = p[c];
+            s_uzm[sl[c]] = 0;
+        }
+        if (im.restart) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                uint32_t mk0 = 0;
+                if (valid[c]) {
+                    const uint32_t *mpos = P.mpos + im.mark_off;
+                    uint32_t lo = 0, hi = E.nmark; // first marker past the start of this row
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (mpos[mid] <= p[c]) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    mk0 = lo; // kept per subsequence: refinement walks, repair launches and k_write start their marker scan here
+                }
+                mk[c] = mk0;
+                s_mk0[sl[c]] = mk0;
+                if (owned[c]) P.submk[im.sub0 + row[c]] = mk0;
             }
-            nblk = 0;
-            nrec = 0;
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) s_mk0[sl[c]] = 0u;
         }
-        stamp(1);
-        s_up[tid] = p;
-        s_uzm[tid] = (uint16_t)(z | (m << 8));
-        ext_p = p; // slot 0 has no predecessor inside the workgroup: its start state stands (the warm-up slots are there for that)
-        ext_zm = z | (m << 8);
-        uint32_t mk0 = 0;
-        decode_row_sync(E, valid, i, p, z, m, nblk, nrec, mk0, [&](uint32_t ph) {
-            if (valid) *ck(ph, tid) = make_uint2(p, z | (m << 6) | ((nblk - cb) << 9) | ((nrec - cr) << 20));
-            cb = nblk;
-            cr = nrec;
-        });
-        s_ep[tid] = p;
-        s_ezm[tid] = (uint16_t)(z | (m << 8));
-        s_cnt[tid] = nblk | (nrec << 16);
-        s_mk0[tid] = mk0;
-        if (im.restart && owned) P.submk[g] = mk0;
+        for (uint32_t ph = 0; ph < nph; ph++) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) phs[c] = ph;
+            decode_windows<(int)C>(E, valid, row, phs, p, z, m, nblk, nrec, mk);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                if (valid[c]) *ck(ph, sl[c]) = make_uint2(p[c], z[c] | (m[c] << 6) | (nblk[c] << 9) | (nrec[c] << 20));
+                tb[c] += nblk[c];
+                tr[c] += nrec[c];
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            s_ep[sl[c]] = p[c];
+            s_ezm[sl[c]] = (uint16_t)(z[c] | (m[c] << 8));
+            s_cnt[sl[c]] = tb[c] | (tr[c] << 16);
+        }
         ndec_total = lim > row0 ? lim - row0 : 0u;
-        nphase_items = valid ? nw : 0u;
     } else {
-        uint4 r = make_uint4(sp, 0u, sp, 0u);
-        uint32_t c = 0;
-        if (valid) {
-            r = P.substate[g];
-            c = P.subcnt[g];
-        }
-        s_mk0[tid] = valid && im.restart ? P.submk[g] : 0u;
-        s_ep[tid] = r.x;
-        s_ezm[tid] = (uint16_t)r.y;
-        s_cnt[tid] = c;
-        s_up[tid] = r.z;
-        s_uzm[tid] = (uint16_t)r.w;
-        ext_p = r.z;
-        ext_zm = r.w;
-        if (tid == 0 && valid && i > 0) {
-            const uint4 pe = P.substate[g - 1];
-            if (pe.x >= sp && pe.x < sp + 32u) { // a record's end always lies inside the next word
-                ext_p = pe.x;
-                ext_zm = pe.y;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t g = im.sub0 + row[c];
+            uint4 r = make_uint4(row[c] * S, 0u, row[c] * S, 0u);
+            uint32_t cn = 0;
+            if (valid[c]) {
+                r = P.substate[g];
+                cn = P.subcnt[g];
+            }
+            s_mk0[sl[c]] = valid[c] && im.restart ? P.submk[g] : 0u;
+            s_ep[sl[c]] = r.x;
+            s_ezm[sl[c]] = (uint16_t)r.y;
+            s_cnt[sl[c]] = cn;
+            s_up[sl[c]] = r.z;
+            s_uzm[sl[c]] = (uint16_t)r.w;
+            if (sl[c] == 0u) {
+                ext_p = r.z;
+                ext_zm = r.w;
+                if (valid[c] && row[c] > 0) {
+                    const uint4 pe = P.substate[g - 1];
+                    if (pe.x >= row[c] * S && pe.x < row[c] * S + 32u) { // a record's end always lies inside the next word
+                        ext_p = pe.x;
+                        ext_zm = pe.y;
+                    }
+                }
             }
         }
     }
@@ -772,50 +1041,71 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 #define HJD_RUN_Q 32u // distances tried (the odd part of the MCU's bit length, in practice)
 #define HJD_RUN_D 96u // longest state period, in subsequences
 #endif
-    static_assert(T / 64 <= 8, "s_wc[8..15] hold the waves' run heads");
-    bool elig = false, any_elig = false; // any_elig: some slot of this workgroup continues a run (ordinary content: none)
-    uint32_t head = 0, runq = 0;
+    bool elig[C], any_elig = false; // any_elig: some slot of this workgroup continues a run (ordinary content: none)
+    uint32_t head[C], runq = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        elig[c] = false;
+        head[c] = 0;
+    }
     if (!im.restart) {
-        const bool full = valid && (i + 1u) * S <= total_bits;
-        const uint32_t nwords = (S >> 5) + 2u;
-        const uint32_t *rw = row_base(E.wbase, i, P.log2_words);
-        const uint32_t w0 = full ? rw[0] : 0u;
-        // distances at which the first word agrees (independent loads: one round trip for all of them) ...
+        uint32_t myq[C];
         static_assert(HJD_RUN_Q <= 32, "one bit per distance");
-        uint32_t cm = 0;
-        if (full) {
-            const uint32_t qn = min(tid, HJD_RUN_Q);
-            for (uint32_t q = 1; q <= qn; q++) cm |= (row_base(E.wbase, i - q, P.log2_words)[0] == w0 ? 1u : 0u) << (q - 1u);
+        const uint32_t nwords = (S >> 5) + 2u;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const bool full = valid[c] && (row[c] + 1u) * S <= total_bits;
+            const uint32_t *rw = row_base(E.wbase, row[c], P.log2_words);
+            const uint32_t w0 = full ? rw[0] : 0u;
+            // distances at which the first word agrees (independent loads: one round trip for all of them) ...
+            uint32_t cm = 0;
+            if (full) {
+                const uint32_t qn = min(sl[c], HJD_RUN_Q);
+                for (uint32_t q = 1; q <= qn; q++) cm |= (row_base(E.wbase, row[c] - q, P.log2_words)[0] == w0 ? 1u : 0u) << (q - 1u);
+            }
+            // ... and of those the smallest at which every word does (ordinary content: none to try)
+            myq[c] = 0;
+            while (__any(cm != 0u && myq[c] == 0u)) {
+                bool t = cm != 0u && myq[c] == 0u;
+                const uint32_t q = t ? (uint32_t)__ffs((int)cm) : 1u;
+                cm &= cm - 1u;
+                const uint32_t *rp = t ? row_base(E.wbase, row[c] - q, P.log2_words) : rw;
+                for (uint32_t k = 1; k < nwords && __any(t); k++)
+                    if (t) t = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
+                if (t) myq[c] = q;
+            }
         }
-        // ... and of those the smallest at which every word does (ordinary content: none to try)
-        uint32_t myq = 0;
-        while (__any(cm != 0u && myq == 0u)) {
-            bool c = cm != 0u && myq == 0u;
-            const uint32_t q = c ? (uint32_t)__ffs((int)cm) : 1u;
-            cm &= cm - 1u;
-            const uint32_t *rp = c ? row_base(E.wbase, i - q, P.log2_words) : rw;
-            for (uint32_t k = 1; k < nwords && __any(c); k++)
-                if (c) c = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
-            if (c) myq = q;
+        if (tid == 0) s_wc[32] = 0xFFFFFFFFu;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++)
+            if (myq[c]) atomicMin(&s_wc[32], myq[c]);
+        __syncthreads();
+        runq = s_wc[32];
+        unsigned long long nb0[C];
+        bool some = false;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            elig[c] = myq[c] != 0u && myq[c] == runq;
+            some = some || elig[c];
+            nb0[c] = __ballot(!elig[c]);
+            const uint32_t vw = wv * C + c;
+            if (lane == 0) s_wc[16u + vw] = nb0[c] ? vw * 64u + 63u - (uint32_t)__clzll((long long)nb0[c]) : 0xFFFFFFFFu;
         }
-        if (tid == 0) s_lst[0] = 0xFFFFFFFFu;
-        __syncthreads();
-        if (myq) atomicMin(&s_lst[0], myq);
-        __syncthreads();
-        runq = s_lst[0];
-        elig = myq != 0u && myq == runq;
-        const unsigned long long nb0 = __ballot(!elig);
-        if (lane == 0) s_wc[8u + wv] = nb0 ? wv * 64u + 63u - (uint32_t)__clzll((long long)nb0) : 0xFFFFFFFFu;
-        any_elig = __syncthreads_or(elig ? 1 : 0) != 0; // also: s_lp / s_lst are the work list from here on
-        const unsigned long long below = nb0 & (~0ull >> (63u - lane));
-        if (below) {
-            head = wv * 64u + 63u - (uint32_t)__clzll((long long)below);
-        } else {
-            for (uint32_t q = wv; q-- > 0u;)
-                if (s_wc[8u + q] != 0xFFFFFFFFu) {
-                    head = s_wc[8u + q];
-                    break;
-                }
+        any_elig = __syncthreads_or(some ? 1 : 0) != 0;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t vw = wv * C + c;
+            const unsigned long long below = nb0[c] & (~0ull >> (63u - lane));
+            if (below) {
+                head[c] = vw * 64u + 63u - (uint32_t)__clzll((long long)below);
+            } else {
+                for (uint32_t q = vw; q-- > 0u;)
+                    if (s_wc[16u + q] != 0xFFFFFFFFu) {
+                        head[c] = s_wc[16u + q];
+                        break;
+                    }
+            }
         }
     }
 
@@ -823,22 +1113,34 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     bool tables_loaded = MODE == 0;
     for (; rounds < 96u; rounds++) {
         // start state every slot should have: its predecessor's current end state
-        uint32_t wp = tid ? s_ep[tid - 1] : ext_p, wzm = tid ? (uint32_t)s_ezm[tid - 1] : ext_zm;
-        if (i == 0) {
-            wp = 0;
-            wzm = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
+        uint32_t wp[C], wzm[C], src[C], shift[C], mep[C], mezm[C];
+        bool dirty[C], moved[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t s = sl[c];
+            wp[c] = s ? s_ep[s - 1] : ext_p;
+            wzm[c] = s ? (uint32_t)s_ezm[s - 1] : ext_zm;
+            if (row[c] == 0) {
+                wp[c] = 0;
+                wzm[c] = 0; // the true start of the scan (loadjpg.cpp:1148-1149)
+            }
+            dirty[c] = valid[c] && (wp[c] != s_up[s] || wzm[c] != (uint32_t)s_uzm[s]);
+            moved[c] = false; // this slot takes the record of a settled slot of its run, moved on, instead of being decoded
+            src[c] = shift[c] = mep[c] = mezm[c] = 0;
         }
-        bool dirty = valid && (wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid]);
-        bool moved = false; // this slot takes the record of a settled slot of its run, moved on, instead of being decoded
-        uint32_t src = 0, shift = 0, mep = 0, mezm = 0;
         if (any_elig) {
-            s_lp[tid] = dirty ? 1u : 0u;
+            __syncthreads(); // everybody has read the work list's place (s_lp doubles as the flags below)
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) s_lp[sl[c]] = dirty[c] ? 1u : 0u;
             __syncthreads();
-            if (elig) {
-                const uint32_t a = head + 1u - runq; // the run's first slot (slots below runq are never elig: a >= 0)
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                if (!elig[c]) continue;
+                const uint32_t s = sl[c];
+                const uint32_t a = head[c] + 1u - runq; // the run's first slot (slots below runq are never elig: a >= 0)
                 uint32_t dsel = 0;
                 bool settled = true; // slots [a, a + d): their records are not about to change, each starts where the one before ends
-                for (uint32_t d = runq; d <= HJD_RUN_D && a + d <= tid && settled; d += runq) {
+                for (uint32_t d = runq; d <= HJD_RUN_D && a + d <= s && settled; d += runq) {
                     for (uint32_t x = a + d - runq; x < a + d; x++) settled = settled && s_lp[x] == 0u;
                     if (settled && s_ep[a + d - 1u] == s_up[a] + d * S && s_ezm[a + d - 1u] == s_uzm[a]) { // the state has come round
                         dsel = d;
@@ -846,29 +1148,41 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     }
                 }
                 if (dsel) {
-                    const uint32_t t = tid - a;
-                    src = a + t % dsel;
-                    shift = (t / dsel) * dsel * S;
-                    wp = s_up[src] + shift;
-                    wzm = s_uzm[src];
-                    mep = s_ep[src] + shift;
-                    mezm = s_ezm[src];
-                    moved = wp != s_up[tid] || wzm != (uint32_t)s_uzm[tid] || mep != s_ep[tid] || mezm != (uint32_t)s_ezm[tid];
-                    dirty = false;
+                    const uint32_t t = s - a;
+                    src[c] = a + t % dsel;
+                    shift[c] = (t / dsel) * dsel * S;
+                    wp[c] = s_up[src[c]] + shift[c];
+                    wzm[c] = s_uzm[src[c]];
+                    mep[c] = s_ep[src[c]] + shift[c];
+                    mezm[c] = s_ezm[src[c]];
+                    moved[c] = wp[c] != s_up[s] || wzm[c] != (uint32_t)s_uzm[s] || mep[c] != s_ep[s] || mezm[c] != (uint32_t)s_ezm[s];
+                    dirty[c] = false;
                 }
             }
             __syncthreads(); // the flags have been read: s_lp is the work list again
         }
-        unsigned long long bal = __ballot(dirty);
-        const bool any_moved = __any(moved);
-        if (lane == 0) s_wc[wv] = (uint32_t)__popcll(bal) | (any_moved ? 0x10000u : 0u);
-        __syncthreads();
-        uint32_t base = 0, n = 0;
+        unsigned long long bal[C];
+        bool any_moved = false;
 #pragma unroll
-        for (uint32_t q = 0; q < T / 64; q++) {
-            const uint32_t c = s_wc[q];
-            base += q < wv ? c & 0xFFFFu : 0u;
-            n += c;
+        for (uint32_t c = 0; c < C; c++) {
+            bal[c] = __ballot(dirty[c]);
+            any_moved = any_moved || moved[c];
+        }
+        any_moved = __any(any_moved);
+        if (lane == 0) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) s_wc[wv * C + c] = (uint32_t)__popcll(bal[c]) | (any_moved ? 0x10000u : 0u);
+        }
+        __syncthreads();
+        uint32_t base[C], n = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) base[c] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < NVW; q++) {
+            const uint32_t cnt = s_wc[q];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) base[c] += q < wv * C + c ? cnt & 0xFFFFu : 0u;
+            n += cnt;
         }
         if (n == 0) break;
         n &= 0xFFFFu; // bits 16..: some slot is moved this round (another round then checks the chain)
@@ -876,91 +1190,120 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             load_tables<true>(ts, s_lut, s_sec);
             tables_loaded = true;
         }
-        if (moved) {
-            for (uint32_t ph = 0; ph < nph; ph++) {
-                const uint2 c = *ck(ph, src);
-                *ck(ph, tid) = make_uint2(c.x + shift, c.y);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t s = sl[c];
+            if (moved[c]) {
+                for (uint32_t ph = 0; ph < nph; ph++) {
+                    const uint2 cc = *ck(ph, src[c]);
+                    *ck(ph, s) = make_uint2(cc.x + shift[c], cc.y);
+                }
+                s_up[s] = wp[c];
+                s_uzm[s] = (uint16_t)wzm[c];
+                s_ep[s] = mep[c];
+                s_ezm[s] = (uint16_t)mezm[c];
+                s_cnt[s] = s_cnt[src[c]];
             }
-            s_up[tid] = wp;
-            s_uzm[tid] = (uint16_t)wzm;
-            s_ep[tid] = mep;
-            s_ezm[tid] = (uint16_t)mezm;
-            s_cnt[tid] = s_cnt[src];
-        }
-        // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's first slots with a new state would go
-        // on through the whole run, one lane, window after window — the run takes the new records in the next round instead.
-        if (elig) s_mark[tid] = (uint8_t)(rounds + 1u);
-        if (dirty) {
-            const uint32_t t = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            s_lp[t] = wp;
-            s_lst[t] = (wzm & 63u) | ((wzm >> 8) << 6) | (tid << 9);
-            s_up[tid] = wp;
-            s_uzm[tid] = (uint16_t)wzm;
-            s_mark[tid] = (uint8_t)(rounds + 1u);
+            // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's first slots with a new state would go
+            // on through the whole run, one lane, window after window — the run takes the new records in the next round instead.
+            if (elig[c]) s_mark[s] = (uint8_t)(rounds + 1u);
+            if (dirty[c]) {
+                const uint32_t t = base[c] + (uint32_t)__popcll(bal[c] & ((1ull << lane) - 1ull));
+                s_lp[t] = wp[c];
+                s_lst[t] = (wzm[c] & 63u) | ((wzm[c] >> 8) << 6) | (s << 9);
+                s_up[s] = wp[c];
+                s_uzm[s] = (uint16_t)wzm[c];
+                s_mark[s] = (uint8_t)(rounds + 1u);
+            }
         }
         __syncthreads();
         stamp(0x100 + n);
-        // the round's items: every wave walks its own, window by window
+        // The round's items.  While they fit, one per lane (a sparse round is latency: every item gets a lane's whole issue rate);
+        // the dense rounds C per lane, side by side.
+        const bool dense = n > T;
         uint32_t steps_done = 0;
-        bool live = tid < n;
-        const uint32_t st = live ? s_lst[tid] : 0u;
-        uint32_t p = live ? s_lp[tid] : 0u;
-        __syncthreads(); // the list is in registers: its place is the staging windows' again
-        if (wv * 64u < n) { // waves without work go straight to the barrier
-            uint32_t slot = st >> 9, ph = 0u;
-            uint32_t z = st & 63u, m = (st >> 6) & 7u;
-            uint32_t cn = 0u, co = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
-            uint32_t wmk = live ? s_mk0[slot] : 0u; // the walk's marker scan: never behind the state's position, which only grows
-            for (uint32_t step = 0; __any(live) && step < 65536u; step++) {
-                uint2 old = make_uint2(0xFFFFFFFFu, 0u);
-                if (live) old = *ck(ph, slot); // arrives while the window is decoded
-                uint32_t nblk = 0, nrec = 0;
-                decode_phase_sync(E, live, row0 + slot, ph, p, z, m, nblk, nrec, wmk);
+        auto walk = [&](auto nc_tag) {
+            constexpr int NC = decltype(nc_tag)::value;
+            bool live[NC];
+            uint32_t slot[NC], ph[NC], p[NC], z[NC], m[NC], cn[NC], co[NC], wmk[NC], wrow[NC], nblk[NC], nrec[NC];
+            bool anylive = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const uint32_t t = tid + (uint32_t)c * T;
+                live[c] = t < n;
+                const uint32_t st = live[c] ? s_lst[t] : 0u;
+                p[c] = live[c] ? s_lp[t] : 0u;
+                slot[c] = st >> 9;
+                ph[c] = 0u;
+                z[c] = st & 63u;
+                m[c] = (st >> 6) & 7u;
+                cn[c] = co[c] = 0u; // blocks | records << 16 of this walk / of the previous decode's checkpoints, windows walked so far
+                anylive = anylive || live[c];
+            }
+            __syncthreads(); // the list is in registers: its place is the staging windows' again
+#pragma unroll
+            for (int c = 0; c < NC; c++) wmk[c] = live[c] ? s_mk0[slot[c]] : 0u; // the walk's marker scan: never behind the state's position, which only grows
+            if (!__any(anylive)) return; // waves without work go straight to the barrier
+            for (uint32_t step = 0; __any(anylive) && step < 65536u; step++) {
+                uint2 old[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    old[c] = make_uint2(0xFFFFFFFFu, 0u);
+                    if (live[c]) old[c] = *ck(ph[c], slot[c]); // arrives while the window is decoded
+                    wrow[c] = row0 + slot[c];
+                }
+                decode_windows<NC>(E, live, wrow, ph, p, z, m, nblk, nrec, wmk);
                 steps_done++;
-                if (live) {
+                anylive = false;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (!live[c]) continue;
                     nphase_items++;
-                    cn += nblk | (nrec << 16);
-                    const uint32_t st9 = z | (m << 6);
-                    const bool met = p == old.x && st9 == (old.y & 511u);
-                    co += ((old.y >> 9) & 2047u) | ((old.y >> 20) << 16);
-                    *ck(ph, slot) = make_uint2(p, st9 | (nblk << 9) | (nrec << 20));
+                    cn[c] += nblk[c] | (nrec[c] << 16);
+                    const uint32_t st9 = z[c] | (m[c] << 6);
+                    const bool met = p[c] == old[c].x && st9 == (old[c].y & 511u);
+                    co[c] += ((old[c].y >> 9) & 2047u) | ((old[c].y >> 20) << 16);
+                    *ck(ph[c], slot[c]) = make_uint2(p[c], st9 | (nblk[c] << 9) | (nrec[c] << 20));
                     if (met) {
                         // in step with the previous decode from here on: its end state stands, its totals change by the
                         // difference over the windows walked (field-wise: no field of the sum can borrow)
-                        s_cnt[slot] = s_cnt[slot] + cn - co;
-                        live = false;
-                    } else if (ph + 1u < nph) {
-                        ph++;
+                        s_cnt[slot[c]] = s_cnt[slot[c]] + cn[c] - co[c];
+                        live[c] = false;
+                    } else if (ph[c] + 1u < nph) {
+                        ph[c]++;
                     } else { // end of the subsequence with a state of its own
-                        s_ep[slot] = p;
-                        s_ezm[slot] = (uint16_t)(z | (m << 8));
-                        s_cnt[slot] = cn;
-                        const uint32_t nx = slot + 1u;
-                        live = nx < T && row0 + nx < lim && s_mark[nx] != rounds + 1u; // walk on: nobody else works on nx this round
-                        if (live) {
+                        s_ep[slot[c]] = p[c];
+                        s_ezm[slot[c]] = (uint16_t)(z[c] | (m[c] << 8));
+                        s_cnt[slot[c]] = cn[c];
+                        const uint32_t nx = slot[c] + 1u;
+                        live[c] = nx < NS && row0 + nx < lim && s_mark[nx] != rounds + 1u; // walk on: nobody else works on nx this round
+                        if (live[c]) {
                             s_mark[nx] = (uint8_t)(rounds + 1u);
-                            s_up[nx] = p;
-                            s_uzm[nx] = (uint16_t)(z | (m << 8));
-                            slot = nx;
-                            ph = 0u;
-                            cn = 0u;
-                            co = 0u;
+                            s_up[nx] = p[c];
+                            s_uzm[nx] = (uint16_t)(z[c] | (m[c] << 8));
+                            slot[c] = nx;
+                            ph[c] = 0u;
+                            cn[c] = 0u;
+                            co[c] = 0u;
                         }
                     }
+                    anylive = anylive || live[c];
                 }
             }
-        }
+        };
+        if (dense) walk(std::integral_constant<int, (int)C>{});
+        else walk(std::integral_constant<int, 1>{});
         stamp(0x10000 + steps_done); // wave 0's windows
         __syncthreads();
         stamp(0x20000);
     }
     {   // diagnostics: windows walked by all lanes -> subsequence decodes
         __syncthreads();
-        if (tid == 0) s_wc[0] = 0u;
+        if (tid == 0) s_wc[32] = 0u;
         __syncthreads();
-        if (nphase_items) atomicAdd(&s_wc[0], nphase_items);
+        if (nphase_items) atomicAdd(&s_wc[32], nphase_items);
         __syncthreads();
-        ndec_total += s_wc[0] / nph;
+        ndec_total += s_wc[32] / nph;
         __syncthreads();
     }
 
@@ -969,60 +1312,68 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         // sums over the windows' block / record counts; the sums over everything BEFORE a final-pass workgroup come from
         // per-workgroup totals (P.wgsum, zeroed by k_unstuff_count).  A final-pass workgroup covers G
         // subsequences, which a synchronisation workgroup's range [own0, own1) cuts anywhere: LDS atomics per group, then one
-        // global atomic per group and counter.  (Round 2 left this to a launch of its own — a 512-lane, 60 KB-LDS gate that
-        // sat 0.2 ms waiting for a CU beside the other streams' kernels.  A stale workgroup border is still caught: k_write
-        // checks the induction step for every subsequence and the host re-synchronises.)
+        // global atomic per group and counter.  A stale workgroup border is still caught: k_write
+        // checks the induction step for every subsequence and the host re-synchronises.
         const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows); // subsequences per final-pass workgroup (powers of two)
         const uint32_t wq0 = own0 / G;
         __syncthreads(); // everyone is done with the work list
-        s_lp[tid] = 0u;
-        s_lst[tid] = 0u;
-        __syncthreads();
-        if (owned) {
-            uint32_t sb, sr;
-            subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, tid)->y; }, sb, sr);
-            atomicAdd(&s_lp[i / G - wq0], sb);
-            atomicAdd(&s_lst[i / G - wq0], sr);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            s_lp[sl[c]] = 0u;
+            s_lst[sl[c]] = 0u;
         }
         __syncthreads();
-        const uint32_t wq = wq0 + tid;
-        if (tid <= (own1 - 1u) / G - wq0 && wq < im.nwritewg && (s_lp[tid] | s_lst[tid])) {
-            atomicAdd(&P.wgsum[im.writewg0 + wq].x, s_lp[tid]);
-            atomicAdd(&P.wgsum[im.writewg0 + wq].y, s_lst[tid]);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++)
+            if (owned[c]) {
+                uint32_t sb, sr;
+                const uint32_t s = sl[c];
+                subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, s)->y; }, sb, sr);
+                atomicAdd(&s_lp[row[c] / G - wq0], sb);
+                atomicAdd(&s_lst[row[c] / G - wq0], sr);
+            }
+        __syncthreads();
+        for (uint32_t t = tid; t < NS; t += T) {
+            const uint32_t wq = wq0 + t;
+            if (t <= (own1 - 1u) / G - wq0 && wq < im.nwritewg && (s_lp[t] | s_lst[t])) {
+                atomicAdd(&P.wgsum[im.writewg0 + wq].x, s_lp[t]);
+                atomicAdd(&P.wgsum[im.writewg0 + wq].y, s_lst[t]);
+            }
         }
         if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
     }
     if (MODE == 2) {
         // The same totals after a repair (host re-synchronisation): written, not added — a repair workgroup holds whole groups.
         const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows);
-        uint32_t sb = 0, sr = 0;
-        if (valid) subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, tid)->y; }, sb, sr);
-        const uint32_t ib = wave_incl_scan(sb), ir = wave_incl_scan(sr);
         __syncthreads(); // everyone is done with the work list
-        s_lp[tid] = ib;
-        s_lst[tid] = ir;
-        __syncthreads();
-        if ((tid & (G - 1u)) == 0) {
-            uint32_t tb = 0, tr = 0;
-            if (G >= 64u) {
-                for (uint32_t q = 0; q < G / 64u; q++) {
-                    tb += s_lp[tid + 64u * q + 63u];
-                    tr += s_lst[tid + 64u * q + 63u];
-                }
-            } else {
-                tb = s_lp[tid + G - 1u] - (lane ? s_lp[tid - 1u] : 0u);
-                tr = s_lst[tid + G - 1u] - (lane ? s_lst[tid - 1u] : 0u);
-            }
-            const uint32_t wq = wg * (T / G) + tid / G;
-            if (wq < im.nwritewg) P.wgsum[im.writewg0 + wq] = make_uint2(tb, tr);
-            if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            uint32_t sb = 0, sr = 0;
+            const uint32_t s = sl[c];
+            if (valid[c]) subseq_totals(nph, P.write_windows, [&](uint32_t ph) { return ck(ph, s)->y; }, sb, sr);
+            s_lp[s] = sb;
+            s_lst[s] = sr;
         }
+        __syncthreads();
+        for (uint32_t t = tid; t * G < NS; t += T) { // one lane per final-pass workgroup of this repair workgroup
+            uint32_t tb = 0, tr = 0;
+            for (uint32_t q = 0; q < G; q++) {
+                tb += s_lp[t * G + q];
+                tr += s_lst[t * G + q];
+            }
+            const uint32_t wq = wg * (NS / G) + t;
+            if (wq < im.nwritewg) P.wgsum[im.writewg0 + wq] = make_uint2(tb, tr);
+        }
+        if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
     }
     if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
-    if (owned) {
-        P.substate[g] = make_uint4(s_ep[tid], (uint32_t)s_ezm[tid], s_up[tid], (uint32_t)s_uzm[tid]);
-        P.subcnt[g] = s_cnt[tid];
-    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++)
+        if (owned[c]) {
+            const uint32_t s = sl[c], g = im.sub0 + row[c];
+            P.substate[g] = make_uint4(s_ep[s], (uint32_t)s_ezm[s], s_up[s], (uint32_t)s_uzm[s]);
+            P.subcnt[g] = s_cnt[s];
+        }
     if (tid == 0) { // diagnostics
         atomicAdd(&P.st[ii].sync_decodes, ndec_total);
         atomicAdd(&P.st[ii].sync_iters, rounds);
@@ -1030,11 +1381,11 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     }
 }
 
-__global__ __launch_bounds__(HJD_SYNC_WG) void k_sync(HjdParams P) { sync_body<0>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_sync(HjdParams P) { sync_body<0>(P); }
 
 // the repair pass is its own kernel symbol so that profiles tell the two apart
-__global__ __launch_bounds__(HJD_SYNC_WG) void k_repair(HjdParams P) { sync_body<1>(P); }
-__global__ __launch_bounds__(HJD_SYNC_WG) void k_repair_totals(HjdParams P) { sync_body<2>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair(HjdParams P) { sync_body<1>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair_totals(HjdParams P) { sync_body<2>(P); }
 
 // ---- stage 3: final entropy decode, coefficients out ------------------------------------------
 
@@ -1211,13 +1562,13 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (!nwg) return 0;
     if (mode == 0) {
         if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
-        hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
+        hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
     } else if (mode == 1) {
         if (set_dyn_lds(1, reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
-        hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
+        hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
     } else {
         if (set_dyn_lds(2, reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
-        hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_WG), P.lds_bytes_sync, s, P);
+        hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
     }
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;

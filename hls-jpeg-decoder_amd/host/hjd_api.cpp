@@ -693,8 +693,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        // k_sync: five word arrays + the u8 marks + 32 words, then the staging windows (whose first 2 T words double as the work list)
-        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 32 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        // k_sync: five word arrays + the u8 marks + 96 words (scratch, block tables), then one staging window per slot (the first
+        // 2 x HJD_SYNC_WG words of which double as the work list)
+        P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 96 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
         P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
