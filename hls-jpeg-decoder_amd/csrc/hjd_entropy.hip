@@ -605,9 +605,12 @@ __device__ __forceinline__ void sync_window(SyncChain (&ch)[NC], const uint32_t 
 }
 
 // One chain per lane (HJD_SYNC_C = 1, and every sparse refinement round): the same loop, instruction by instruction.  A wave issues
-// one instruction of any kind every 4-5 cycles whatever the other waves do, so the time of a walk is its instruction count:
-// the compiler's version of the loop above is 58 instructions per step (copies for its loop-carried values, nine for the
-// wave-uniform test of a 0.2 % case, separate shift / mask / add for what v_bfe_u32 and v_lshl_add_u32 do in one); this is 42.
+// one instruction of any kind every 4-5 cycles whatever the other waves do, so the time of a walk is its instruction count plus
+// the LDS round trip of the table look-up that every step waits for: the compiler's version of the loop above is 58
+// instructions per step (copies for its loop-carried values, nine for the wave-uniform test of a 0.2 % case, separate shift /
+// mask / add for what v_bfe_u32 and v_lshl_add_u32 do in one) and waits with nothing else to do.  Here a step is 40
+// instructions, and the ones that do not feed the next look-up (record and block counts, the bit position and the test for the
+// window's end, the conditions for a two-symbol step) are the PREVIOUS step's, issued between the look-up and the wait for it.
 // v120-v123 receive the block table entry (ds_read_b128 needs four consecutive registers; inline assembly cannot name the
 // parts of a 128-bit operand).  All waits for the LDS reads issued here are inside: the compiler does not count them.
 template <>
@@ -616,25 +619,30 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
     SyncChain &c = ch[0];
     const uint32_t plim = pend[0] > 32u ? pend[0] - 32u : 0u;
     const uint32_t secm = sec_addr - 2u * HJD_SEC_SIZE; // second-level table `sub` (1-based) starts at sec_addr + (sub - 1) * 2 * HJD_SEC_SIZE
-    uint32_t win, a, w, e, tot, t, nw;
-    unsigned long long act, pm, sv;
+    uint32_t tb = c.z == 0u ? c.dcb : c.acb;            // table of the next symbol: carried from step to step
+    uint32_t win, a, w, nw, t;
+    uint32_t e = 0u, tot = 0u;                          // the previous step's entry and length: its counts are added a step late
+    unsigned long long act, pm, sv, bm = 0ull;
     static_assert(HJD_LUT_BITS == 11 && HJD_SEC_BITS == 5, "field positions below");
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n"
         "1:\n\t"
-        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"       // lanes with bits left in the window
         "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"   // the next 32 bits
-        "v_cmp_eq_u32_e32 vcc, 0, %[z]\n\t"
-        "s_cmp_eq_u64 %[act], 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
-        "v_cndmask_b32_e32 %[t], %[acb], %[dcb], vcc\n\t"  // z == 0: DC table
         "v_bfe_u32 %[a], %[win], 21, 11\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
-        "v_lshl_add_u32 %[a], %[a], 2, %[t]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[tb]\n\t"
         "ds_read_b32 %[w], %[a]\n\t"                       // [0] | [1] << 16
         "ds_read_b32 %[nw], %[nxa]\n\t"                    // next stream word
         "ds_read_b128 v[120:123], %[mi]\n\t"               // next block's tables
+        // while the look-up is under way: what the previous step left to do
+        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
+        "v_bfe_u32 %[t], %[e], 14, 2\n\t"
+        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[bm]\n\t"
+        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"       // lanes with bits left in the window
+        "v_add_u32_e32 %[nrec], %[nrec], %[t]\n\t"
+        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
+        "s_cmp_eq_u64 %[act], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
         "s_and_b64 vcc, vcc, %[pm]\n\t"                    // two symbols as one step
         "s_waitcnt lgkmcnt(2)\n\t"
         "v_lshrrev_b32_e32 %[e], 16, %[w]\n\t"
@@ -658,33 +666,28 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         "s_mov_b64 exec, %[sv]\n"
         "2:\n\t"
         "v_cndmask_b32_e64 %[e], 0, %[e], %[act]\n\t"      // a lane at the end of its window stands still
-        // three short chains, dealt out alternately: the reader (tot -> sh -> roll), the block (advance -> z -> end of block),
-        // the record count
         "v_and_b32_e32 %[tot], 31, %[e]\n\t"
         "v_bfe_u32 %[t], %[e], 5, 7\n\t"
-        "v_bfe_u32 %[a], %[e], 14, 2\n\t"
         "v_sub_u32_e32 %[sh], %[sh], %[tot]\n\t"
         "v_add_u32_e32 %[z], %[z], %[t]\n\t"
-        "v_add_u32_e32 %[nrec], %[nrec], %[a]\n\t"
-        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
         "v_cmp_gt_i32_e32 vcc, 0, %[sh]\n\t"               // the reader rolls on to the next word
-        "v_cmp_lt_u32_e64 %[pm], 63, %[z]\n\t"             // end of block
+        "v_cmp_lt_u32_e64 %[bm], 63, %[z]\n\t"             // end of block
         "v_and_b32_e32 %[t], 0x100, %[sh]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cndmask_b32_e32 %[hi], %[hi], %[lo], vcc\n\t"
         "v_add_u32_e32 %[nxa], %[nxa], %[t]\n\t"
-        "v_cndmask_b32_e64 %[z], %[z], 0, %[pm]\n\t"
+        "v_cndmask_b32_e64 %[tb], %[acb], v120, %[bm]\n\t" // the next symbol: this block's AC table, or the next block's DC table
         "v_cndmask_b32_e32 %[lo], %[lo], %[nw], vcc\n\t"
-        "v_cndmask_b32_e64 %[dcb], %[dcb], v120, %[pm]\n\t"
+        "v_cndmask_b32_e64 %[z], %[z], 0, %[bm]\n\t"
         "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
-        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[pm]\n\t"
-        "v_cndmask_b32_e64 %[mi], %[mi], v122, %[pm]\n\t"
-        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[pm]\n\t"
+        "v_cndmask_b32_e64 %[mi], %[mi], v122, %[bm]\n\t"
+        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[bm]\n\t"
         "s_branch 1b\n"
         "3:\n\t"
-        : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [dcb] "+v"(c.dcb),
-          [acb] "+v"(c.acb), [mi] "+v"(c.mi), [nblk] "+v"(c.nblk), [nrec] "+v"(c.nrec), [win] "=&v"(win), [a] "=&v"(a), [w] "=&v"(w),
-          [e] "=&v"(e), [tot] "=&v"(tot), [t] "=&v"(t), [nw] "=&v"(nw), [act] "=&s"(act), [pm] "=&s"(pm), [sv] "=&s"(sv)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [tb] "+v"(tb),
+          [acb] "+v"(c.acb), [mi] "+v"(c.mi), [nblk] "+v"(c.nblk), [nrec] "+v"(c.nrec), [e] "+v"(e), [tot] "+v"(tot), [bm] "+s"(bm),
+          [win] "=&v"(win), [a] "=&v"(a), [w] "=&v"(w), [t] "=&v"(t), [nw] "=&v"(nw), [act] "=&s"(act), [pm] "=&s"(pm), [sv] "=&s"(sv)
         : [pend] "v"(pend[0]), [plim] "v"(plim), [secm] "v"(secm)
         : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
 }
