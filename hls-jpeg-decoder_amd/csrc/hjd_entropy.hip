@@ -625,24 +625,12 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
     unsigned long long act, pm, sv, bm = 0ull;
     static_assert(HJD_LUT_BITS == 11 && HJD_SEC_BITS == 5, "field positions below");
     asm volatile(
-        "s_waitcnt lgkmcnt(0)\n"
-        "1:\n\t"
-        "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"   // the next 32 bits
-        "v_bfe_u32 %[a], %[win], 21, 11\n\t"
-        "v_lshl_add_u32 %[a], %[a], 2, %[tb]\n\t"
-        "ds_read_b32 %[w], %[a]\n\t"                       // [0] | [1] << 16
-        "ds_read_b32 %[nw], %[nxa]\n\t"                    // next stream word
-        "ds_read_b128 v[120:123], %[mi]\n\t"               // next block's tables
-        // while the look-up is under way: what the previous step left to do
-        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
-        "v_bfe_u32 %[t], %[e], 14, 2\n\t"
-        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[bm]\n\t"
-        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"       // lanes with bits left in the window
-        "v_add_u32_e32 %[nrec], %[nrec], %[t]\n\t"
-        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
-        "s_cmp_eq_u64 %[act], 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
+        // One taken branch costs a wave as much as four instructions (tools/lat_probe.hip: 30 cycles against 8), so the loop is laid
+        // out with a single one per step: its back edge is the test for the window's end, and the second-level look-up (0.2 % of
+        // the symbols) sits behind the loop, reached by a branch that is not taken otherwise.
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_branch 1f\n"
+        "2:\n\t"                                             // ---- the look-up has been issued: is the step taken at all?
         "s_and_b64 vcc, vcc, %[pm]\n\t"                    // two symbols as one step
         "s_waitcnt lgkmcnt(2)\n\t"
         "v_lshrrev_b32_e32 %[e], 16, %[w]\n\t"
@@ -650,21 +638,8 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         "v_and_b32_e32 %[tot], 31, %[e]\n\t"
         "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
         "s_and_b64 %[pm], vcc, %[act]\n\t"                 // a live lane with a code longer than HJD_LUT_BITS?
-        "s_cbranch_scc0 2f\n\t"
-        "s_and_saveexec_b64 %[sv], %[pm]\n\t"              // second-level table on the next HJD_SEC_BITS bits
-        "v_bfe_u32 %[t], %[e], 5, 11\n\t"                  // 1 + table index, 0 = no code has this prefix
-        "v_bfe_u32 %[a], %[win], 16, 5\n\t"
-        "v_lshl_add_u32 %[a], %[t], 5, %[a]\n\t"
-        "v_lshl_add_u32 %[a], %[a], 1, %[secm]\n\t"
-        "ds_read_u16 %[a], %[a]\n\t"
-        "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cndmask_b32_e32 %[e], 0, %[a], vcc\n\t"
-        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
-        "v_cndmask_b32_e64 %[e], %[e], 16, vcc\n\t"        // no such code: skip 16 bits, the final pass flags it
-        "s_mov_b64 exec, %[sv]\n"
-        "2:\n\t"
+        "s_cbranch_scc1 4f\n"
+        "5:\n\t"
         "v_cndmask_b32_e64 %[e], 0, %[e], %[act]\n\t"      // a lane at the end of its window stands still
         "v_and_b32_e32 %[tot], 31, %[e]\n\t"
         "v_bfe_u32 %[t], %[e], 5, 7\n\t"
@@ -681,8 +656,40 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         "v_cndmask_b32_e64 %[z], %[z], 0, %[bm]\n\t"
         "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
         "v_cndmask_b32_e64 %[mi], %[mi], v122, %[bm]\n\t"
-        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[bm]\n\t"
-        "s_branch 1b\n"
+        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[bm]\n"
+        "1:\n\t"                                             // ---- next look-up
+        "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"   // the next 32 bits
+        "v_bfe_u32 %[a], %[win], 21, 11\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[tb]\n\t"
+        "ds_read_b32 %[w], %[a]\n\t"                       // [0] | [1] << 16
+        "ds_read_b32 %[nw], %[nxa]\n\t"                    // next stream word
+        "ds_read_b128 v[120:123], %[mi]\n\t"               // next block's tables
+        // while the look-up is under way: what the previous step left to do
+        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
+        "v_bfe_u32 %[t], %[e], 14, 2\n\t"
+        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[bm]\n\t"
+        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"       // lanes with bits left in the window
+        "v_add_u32_e32 %[nrec], %[nrec], %[t]\n\t"
+        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
+        "s_cmp_lg_u64 %[act], 0\n\t"
+        "s_cbranch_scc1 2b\n\t"                            // the one taken branch of a step
+        "s_branch 3f\n"
+        "4:\n\t"                                             // ---- second-level table on the next HJD_SEC_BITS bits
+        "s_and_saveexec_b64 %[sv], %[pm]\n\t"
+        "v_bfe_u32 %[t], %[e], 5, 11\n\t"                  // 1 + table index, 0 = no code has this prefix
+        "v_bfe_u32 %[a], %[win], 16, 5\n\t"
+        "v_lshl_add_u32 %[a], %[t], 5, %[a]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 1, %[secm]\n\t"
+        "ds_read_u16 %[a], %[a]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 %[e], 0, %[a], vcc\n\t"
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
+        "v_cndmask_b32_e64 %[e], %[e], 16, vcc\n\t"        // no such code: skip 16 bits, the final pass flags it
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_branch 5b\n"
         "3:\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [tb] "+v"(tb),
