@@ -14,10 +14,11 @@
 //              slot = u*8+v is the coefficient's place after DeZigZag + TransformArray (loadjpg.cpp:156-180), u the
 //              horizontal frequency; all ones = padding), every subsequence's run rounded up to HJD_REC_RUN
 //              records so that it is written in aligned 16-byte stores
-//   blk      : one uint4 per block: x = index of the block's first record, y = the decoded DC difference, z/w = 64-bit mask of
-//              the slots its AC records fill (those decoded by the k_write lane that holds its DC symbol; later ones are flagged
-//              in the record and added by the back end); one extra entry per image closes the last block's record range
-//   dcd      : per block, the DC difference once more as int16 (what the DC prediction kernels read)
+//   blk      : one uint2 per block: x = index of the block's first record, y = the decoded DC difference (int16 in the low half).
+//              Written once and whole (8 bytes) by the k_write lane that decoded the block's DC symbol; read by the DC prediction
+//              kernels (y) and, at the borders of its groups only, by the back end (x).  One extra entry per image closes the
+//              last block's record range.  (Until round 4: 16 bytes with the mask of the slots the block's records fill, and the DC
+//              difference a second time in a 2-byte array of its own — the back end now builds the masks from the records.)
 //   dca      : per block, the DC value after prediction (int16), written by k_dcapply
 //   wgmap    : for every kernel's workgroup numbering, workgroup -> image (one load instead of a search)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
@@ -148,6 +149,5 @@ struct HjdImageState {
 // synchronisation record of one subsequence (substate[]): x = end state bit position (>= end of the
 // subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
-#define HJD_REC_ORPHAN (1u << 29) // the record's block began in an earlier k_write span: its slot is not in the block's mask
 #define HJD_REC_RUN 8 // every k_write lane's run of records is padded to a multiple: a lane stores 32 aligned bytes at a time — a whole
                       // sector (16-byte bursts, round 2, wrote every sector of the record array twice)

@@ -140,30 +140,23 @@ struct WriteCtx {
     uint32_t *ring;
     uint32_t *rec;
     uint32_t rec_cap;
-    uint4 *blk;
-    int16_t *dcd;           // per block: the DC difference again, compact, for the DC prediction kernels (2 bytes per block instead of a 16-byte entry)
+    uint2 *blk;
     uint32_t nblocks;
     const uint8_t *slot_of; // LDS: zig-zag index -> slot u*8+v
-    unsigned long long mask; // slots filled by the records of the block in progress (this subsequence's part of it)
-    uint32_t bfirst;        // first record of the block in progress, or ~0 when the block began in an earlier subsequence
+    uint32_t bfirst;        // first record of the block in progress, or ~0 when the block began in an earlier span
     uint32_t bdc;
-    uint32_t tag;           // block bits of a record: (block & 127) << 22, | HJD_REC_ORPHAN while the block began elsewhere
+    uint32_t tag;           // block bits of a record: (block & 127) << 22
 };
 
-// The entry of block b = (first record, DC difference, 64-bit mask of the slots its records fill), written once and whole by
-// the lane that decoded the block's DC symbol (bfirst != ~0), when the block ends or the lane's span does.  Records of a block
-// that began in an earlier span (one block in five straddles at 512-bit spans) are marked HJD_REC_ORPHAN instead: the back end
-// adds their slots to the block's mask itself before it builds its term lists.  (Global atomics into the entry from the lanes
-// that decode a straddling block's later parts were tried: k_write 15 % slower, against one cheap extra pass over the
-// records in the back end.)
+// The entry of block b = (first record, DC difference), written once and whole — one 8-byte store — by the lane that decoded
+// the block's DC symbol (bfirst != ~0), when the block ends or the lane's span does.  (Rounds 2-3 wrote 16 bytes per block,
+// with the mask of the slots the block's records fill, plus the DC difference once more into a 2-byte array for the DC
+// prediction kernels: k_write wrote 1.8 times its useful bytes, most of the excess in those lone 2- and 16-byte stores.  The
+// back end builds the masks from the records themselves — it touches every record anyway.)
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
-    if (W.bfirst != 0xFFFFFFFFu) {
-        W.blk[b] = make_uint4(W.bfirst, W.bdc, (uint32_t)W.mask, (uint32_t)(W.mask >> 32));
-        W.dcd[b] = (int16_t)W.bdc; // the DC difference once more, compact, for the DC prediction kernels
-    }
+    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu);
     W.bfirst = 0xFFFFFFFFu;
-    W.mask = 0ull;
 }
 
 // Synchronisation form of the decode loop: symbols from state (p, z, m) until p >= end; nblk counts blocks completed, nrec the
@@ -348,8 +341,6 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                             // no lane of a wave takes it on a stream the reference can decode)
                 flags |= HJD_FLAG_OVERRUN;
                 w = HJD_REC_PAD;
-            } else {
-                W.mask |= 1ull << slot;
             }
             static_assert(HJD_REC_RUN == 8, "two 16-byte halves per burst");
             W.ring[(nrec & 7u) * HJD_WRITE_WG] = w;
@@ -375,7 +366,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             write_block_entry(W, nblk);
             nblk++;
             if (nblk == W.nblocks) {
-                W.blk[nblk] = make_uint4(nrec, 0u, 0u, 0u); // end of the last block's records
+                W.blk[nblk] = make_uint2(nrec, 0u); // end of the last block's records
                 end = p;                                    // the image is complete: what follows is not looked at
             }
             m = mnx;
@@ -1505,9 +1496,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         }
     }
 
-    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, P.dcd + im.blk_off,
-                  im.nblocks, s_slot, 0ull, 0xFFFFFFFFu, 0u, 0u};
-    W.tag = ((blk & 127u) << 22) | HJD_REC_ORPHAN; // records before the first DC symbol belong to a block begun in an earlier span
+    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks, s_slot, 0xFFFFFFFFu, 0u, 0u};
+    W.tag = (blk & 127u) << 22; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
     const uint32_t row_bit0 = i * S;
     const uint32_t pend = min(row_bit0 + (ph + WWN) * P.phase_words * 32u, min(row_bit0 + S, total_bits));

@@ -25,8 +25,7 @@ struct HjdParams {
     uint64_t ck_scratch;       // first entry of that scratch area
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
-    uint4 *blk;                // per block: first record index, DC difference, slot mask lo, hi
-    int16_t *dcd;              // per block: DC difference as decoded (k_write)
+    uint2 *blk;                // per block: first record index, DC difference as decoded (k_write)
     int16_t *dca;              // per block: DC value after prediction
     // workgroup -> image for every kernel's workgroup numbering (global numbers, like the off_* below)
     const uint32_t *map_chunk, *map_syncwg, *map_repwg, *map_writewg, *map_dcchunk;

@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t KB = K * nb;
 
-    // block entries (first record, DC difference, slot mask) and predicted DC — independent of the image fields
-    uint4 be = make_uint4(0u, 0u, 0u, 0u);
+    // the group's record range (first record of its first block, first record of the block after its last) and the predicted
+    // DC values — independent of the image fields
+    uint32_t bfirst = 0u;
     int dc = 0;
-    if (tid <= KB) be = P.blk[gm.y + tid];
+    if (tid == 0 || tid == KB) bfirst = P.blk[gm.y + tid].x;
     if (tid < KB) dc = P.dca[gm.y + tid];
     constexpr bool conf = CONF;
     if (tid < 64) {
@@ -265,11 +266,8 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     }
     if (tid < 48) reinterpret_cast<uint32_t *>(&s_qt[0][0])[tid] = reinterpret_cast<const uint32_t *>(&im.qt[0][0])[tid];
     if (tid >= 64 && tid < 128) s_hist[tid - 64] = 0u;
-    if (tid <= KB) {
-        const uint32_t first = min(be.x, im.rec_cap);
-        if (tid == 0) s_range[0] = first;
-        if (tid == KB) s_range[1] = first;
-    }
+    if (tid == 0) s_range[0] = min(bfirst, im.rec_cap);
+    if (tid == KB) s_range[1] = min(bfirst, im.rec_cap);
     uint32_t mycomp = 0;
     if (tid < KB) {
         // tid % nb without a division: nb is 3, 4 or 6 (hf*vf <= 4) and tid < 256, where floor(tid/nb) == tid * ceil(2^16/nb) >> 16
@@ -277,8 +275,8 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
         const uint32_t mm = tid - ((tid * inv) >> 16) * nb;
         mycomp = mm < nby ? 0u : mm - nby + 1u;
         s_comp[tid] = (uint8_t)mycomp;
-        s_mask[tid][0] = be.z & ~1u;
-        s_mask[tid][1] = be.w;
+        s_mask[tid][0] = 0u; // filled from the records below
+        s_mask[tid][1] = 0u;
     }
     __syncthreads();
     if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0 (DequantizeBlock, loadjpg.cpp:144-152: int16 wrap)
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
                 if (w != HJD_REC_PAD && t + k >= r0 && t + k < r1 && rel < KB) {
                     const uint32_t slot = (w >> 16) & 63u;
                     s_coef[rel][slot] = (int16_t)((int)(int16_t)(w & 0xFFFFu) * (int)s_qt[s_comp[rel]][slot]);
-                    if (w & HJD_REC_ORPHAN) atomicOr(&s_mask[rel][slot >> 5], 1u << (slot & 31u)); // its block's entry was written before this record existed
+                    atomicOr(&s_mask[rel][slot >> 5], 1u << (slot & 31u)); // the slots a block's records fill: its term list
                 }
             }
         }

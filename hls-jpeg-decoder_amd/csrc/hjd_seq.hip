@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
     r.n = im.scan_len;
     r.idx = r.res = r.nbits = 0u; // loadjpg.cpp:1148-1149
     uint32_t *rec = P.rec + im.rec_off;
-    uint4 *blk = P.blk + im.blk_off;
+    uint2 *blk = P.blk + im.blk_off;
     int16_t *dca = P.dca + im.blk_off;
     int prev[3] = {0, 0, 0}; // :1159-1162, never reset afterwards
     uint32_t nrec = 0, flags = 0;
@@ -147,7 +147,6 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
         const uint32_t comp = m < im.nby ? 0u : m - im.nby + 1u; // DecodeMCU order, :945-997
         const uint32_t tdc = (ts.slot_pack >> (comp * 8u)) & 7u, tac = (ts.slot_pack >> (comp * 8u + 4u)) & 7u;
         const uint32_t first = nrec;
-        uint32_t mlo = 0, mhi = 0;
 
         if (restart && r.on_marker()) r.resync(); // block-start check, :535-550
 
@@ -195,15 +194,13 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
                 else flags |= HJD_FLAG_OVERRUN;
                 nrec++;
                 nr++;
-                if (slot < 32u) mlo |= 1u << slot;
-                else mhi |= 1u << (slot - 32u);
             }
             if (flags) break;
         }
-        blk[b] = make_uint4(first, 0u, mlo, mhi);
+        blk[b] = make_uint2(first, 0u); // the back end takes the predicted DC from dca[], the slots its records fill from the records
         dca[b] = (int16_t)dc;
     }
-    blk[im.nblocks] = make_uint4(min(nrec, im.rec_cap), 0u, 0u, 0u);
+    blk[im.nblocks] = make_uint2(min(nrec, im.rec_cap), 0u);
     HjdImageState &st = P.st[ii];
     // replaces the parallel path's verdict for this image; what the unstuff stage found (BAD_MARKER) stays, because a host
     // re-synchronisation re-runs everything after that stage and must send the image here again

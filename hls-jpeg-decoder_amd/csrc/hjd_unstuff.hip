@@ -252,21 +252,23 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
 // (loadjpg.cpp:619-667, :1159-1162), int16 wrap (loadjpg.cpp:664-665) = prefix sums mod 2^16 over the
 // blocks of each component in decode order.  Two passes over chunks of HJD_DC_CHUNK MCUs:
 // k_dcsum (per-chunk totals), k_dcapply (totals of the earlier chunks + scan inside the chunk).
-// The differences sit in the compact array dcd[] (written by k_write next to the blocks' 16-byte entries: 2 bytes per
-// block to read here, not 16); the predicted values go to the compact array dca[] (a thread's 2-byte stores are contiguous:
-// whole sectors leave the wave).
+// The differences sit in the blocks' 8-byte entries (blk[].y, written by k_write together with the first-record index: one store
+// per block); the predicted values go to the compact array dca[] (a thread's 2-byte stores are contiguous: whole sectors
+// leave the wave).
 
 #define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
 
-__device__ __forceinline__ void dc_thread_sums(const int16_t *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+__device__ __forceinline__ uint32_t dc_diff(const uint2 &e) { return (uint32_t)(int)(int16_t)e.y; }
+
+__device__ __forceinline__ void dc_thread_sums(const uint2 *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
                                                uint32_t &y, uint32_t &cb, uint32_t &cr)
 {
     y = cb = cr = 0;
     for (uint32_t mc = m0; mc < m1; mc++) {
-        const int16_t *q = d + (size_t)mc * nb;
-        for (uint32_t k = 0; k < nby; k++) y += (uint32_t)(int)q[k];
-        cb += (uint32_t)(int)q[nby];
-        cr += (uint32_t)(int)q[nby + 1];
+        const uint2 *q = d + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) y += dc_diff(q[k]);
+        cb += dc_diff(q[nby]);
+        cr += dc_diff(q[nby + 1]);
     }
 }
 
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
     const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     uint32_t y, cb, cr, ty, tcb, tcr;
-    dc_thread_sums(P.dcd + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
+    dc_thread_sums(P.blk + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
     block_excl_scan(y, s_w, &ty);
     block_excl_scan(cb, s_w, &tcb);
     block_excl_scan(cr, s_w, &tcr);
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     block_excl_scan(pcb, s_w, &bcb);
     block_excl_scan(pcr, s_w, &bcr);
     const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
-    const int16_t *d = P.dcd + im.blk_off;
+    const uint2 *d = P.blk + im.blk_off;
     int16_t *o = P.dca + im.blk_off;
     uint32_t y, cb, cr;
     dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
@@ -320,15 +322,15 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     cb = bcb + block_excl_scan(cb, s_w, &t);
     cr = bcr + block_excl_scan(cr, s_w, &t);
     for (uint32_t mc = m0; mc < m1; mc++) {
-        const int16_t *q = d + (size_t)mc * nb;
+        const uint2 *q = d + (size_t)mc * nb;
         int16_t *w = o + (size_t)mc * nb;
         for (uint32_t k = 0; k < nby; k++) {
-            y += (uint32_t)(int)q[k];
+            y += dc_diff(q[k]);
             w[k] = (int16_t)y; // int16 wrap of the predictor (loadjpg.cpp:664-665)
         }
-        cb += (uint32_t)(int)q[nby];
+        cb += dc_diff(q[nby]);
         w[nby] = (int16_t)cb;
-        cr += (uint32_t)(int)q[nby + 1];
+        cr += dc_diff(q[nby + 1]);
         w[nby + 1] = (int16_t)cr;
     }
 }

@@ -206,8 +206,8 @@ struct hjd_batch {
     uint2 *d_ckpt = nullptr;
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
-    uint4 *d_blk = nullptr;
-    int16_t *d_dca = nullptr, *d_dcd = nullptr;
+    uint2 *d_blk = nullptr;
+    int16_t *d_dca = nullptr;
     uint32_t *d_rec = nullptr;
     uint32_t *d_maps = nullptr; // workgroup -> image tables of all kernels, one allocation
     // A batch object can be re-prepared in place (hjd_batch_reset): slabs are only re-allocated when the new
@@ -472,7 +472,6 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_blk);
     (void)hipFree(b->d_dca);
-    (void)hipFree(b->d_dcd);
     (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
     if (b->seq_stream) (void)hipStreamDestroy(b->seq_stream);
@@ -720,13 +719,11 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * ((size_t)b->nsub * nph + (size_t)b->nsyncwg * nph * K + 1)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
-    need(slab_reserve(b, b->d_blk, sizeof(uint4) * (blk_cur + 1)));
+    need(slab_reserve(b, b->d_blk, sizeof(uint2) * (blk_cur + 1)));
     need(slab_reserve(b, b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
-    need(slab_reserve(b, b->d_dcd, sizeof(int16_t) * (blk_cur + 2)));
     need(slab_reserve(b, b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
     if (rcs != HJD_OK) return rcs;
-    HIPCHK(hipMemsetAsync(b->d_blk, 0, sizeof(uint4) * (blk_cur + 1), up));
-    HIPCHK(hipMemsetAsync(b->d_dcd, 0, sizeof(int16_t) * (blk_cur + 2), up));
+    HIPCHK(hipMemsetAsync(b->d_blk, 0, sizeof(uint2) * (blk_cur + 1), up));
     std::vector<uint32_t> maps;
     {   // workgroup -> image for every kernel's workgroup numbering; IDCT groups also get their first block
         size_t off_chunk = 0, off_sync, off_rep, off_write, off_dc, off_group;
@@ -827,7 +824,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.rec = b->d_rec;
     P.blk = b->d_blk;
     P.dca = b->d_dca;
-    P.dcd = b->d_dcd;
     P.dcsum = b->d_dcsum;
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
@@ -1373,12 +1369,12 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     DeviceGuard guard(b->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     // test hook: rebuild the dense DCT[] rows from the device's sparse form (records + offsets + predicted DC)
-    std::vector<uint4> blk(im.nblocks + 1);
+    std::vector<uint2> blk(im.nblocks + 1);
     std::vector<uint32_t> rec(im.rec_cap);
     uint8_t slot_to_zz[64];
     for (int k = 0; k < 64; k++) slot_to_zz[kZzToSlot[k]] = (uint8_t)k;
     std::vector<int16_t> dca(im.nblocks);
-    HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint2), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(dca.data(), b->d_dca + im.blk_off, dca.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rec.data(), b->d_rec + im.rec_off, rec.size() * 4, hipMemcpyDeviceToHost));
     memset(dst, 0, ne * 2);
