@@ -40,6 +40,8 @@
                                // has HJD_SYNC_WG / HJD_SYNC_C lanes
 #endif
 #define HJD_SYNC_THREADS (HJD_SYNC_WG / HJD_SYNC_C)
+#define HJD_SYNC_WG_SMALL 64   // slots of the small synchronisation workgroup: one wave, for images whose scan is at most that many
+                               // subsequences less the warm-up (HjdImage::sync_small)
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
@@ -112,7 +114,7 @@ struct HjdImage {
     uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
     uint32_t rec_cap;       // records reserved
     uint32_t conformant;    // hjd_options.conformant: DC reset at RSTn, true-cosine rounding IDCT, rounding colour
-    uint32_t pad1;
+    uint32_t sync_small;    // 1: the image's one synchronisation workgroup is a small one (k_sync_small, its own numbering)
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)

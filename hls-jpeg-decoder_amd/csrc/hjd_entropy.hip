@@ -836,20 +836,25 @@ __device__ __forceinline__ void subseq_totals(uint32_t nph, uint32_t ww, CkY cky
 //     one is an item of this round itself: a state change runs down the chain inside one round instead of one
 //     subsequence per round.
 // MODE 1 / 2 (repair) use the same machinery on the records and checkpoints k_sync left (no round 0, no warm-up slots).
-template <int MODE>
+// NS_ = slots of the workgroup: HJD_SYNC_WG, or HJD_SYNC_WG_SMALL for the images whose whole scan fits one small workgroup
+// (k_sync_small: a thumbnail has a dozen subsequences; in a workgroup of 512 lanes it paid for 32 KB of tables, eight waves at
+// every barrier and a slot on a CU's two — 8192 images of 64 x 64, 3.8 M images/s, most of it this kernel).
+template <int MODE, uint32_t NS_>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    constexpr uint32_t NS = HJD_SYNC_WG;      // slots
+    constexpr bool SMALL = NS_ != HJD_SYNC_WG;
+    constexpr uint32_t NS = NS_;              // slots
     constexpr uint32_t C = HJD_SYNC_C;        // chains per lane
-    constexpr uint32_t T = HJD_SYNC_THREADS;  // lanes
+    constexpr uint32_t T = NS / C;            // lanes
     constexpr uint32_t NVW = NS / 64u;        // "virtual waves": 64 consecutive slots = chain c of wave wv, vw = wv * C + c
     static_assert(NS <= 1024, "work items carry their slot in 10 bits");
     static_assert(NS % (64 * C) == 0 && NVW <= 16, "whole waves; the per-virtual-wave scratch holds 16");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t bid = blockIdx.x + (MODE == 0 ? P.off_syncwg : P.off_repwg);
-    const int ii = (int)(MODE == 0 ? P.map_syncwg[bid] : P.map_repwg[bid]);
+    static_assert(MODE == 0 || !SMALL, "the repair kernels have one size");
+    const uint32_t bid = blockIdx.x + (MODE == 0 ? (SMALL ? P.off_syncwg_small : P.off_syncwg) : P.off_repwg);
+    const int ii = (int)(MODE == 0 ? (SMALL ? P.map_syncwg_small[bid] : P.map_syncwg[bid]) : P.map_repwg[bid]);
     static_assert(HJD_SYNC_WG % HJD_WRITE_WG == 0, "a repair workgroup covers whole final-pass workgroups");
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - (MODE == 0 ? im.syncwg0 : im.repwg0);
@@ -922,7 +927,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 
     uint32_t ext_p = row0 * S, ext_zm = 0; // start state offered to slot 0 from outside the workgroup
     // HJD_SYNC_PROF (diagnostics, tools/sync_profile.py): shader-clock stamps of this workgroup's stages
-    unsigned long long *dbg = (MODE == 0 && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
+    unsigned long long *dbg = (MODE == 0 && !SMALL && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
     uint32_t dbg_k = 0;
     auto stamp = [&](unsigned long long extra) {
         if (dbg && tid == 0 && dbg_k < 30u) {
@@ -1382,11 +1387,12 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     }
 }
 
-__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_sync(HjdParams P) { sync_body<0>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_sync(HjdParams P) { sync_body<0, HJD_SYNC_WG>(P); }
+__global__ __launch_bounds__(HJD_SYNC_WG_SMALL / HJD_SYNC_C) void k_sync_small(HjdParams P) { sync_body<0, HJD_SYNC_WG_SMALL>(P); }
 
 // the repair pass is its own kernel symbol so that profiles tell the two apart
-__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair(HjdParams P) { sync_body<1>(P); }
-__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair_totals(HjdParams P) { sync_body<2>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair(HjdParams P) { sync_body<1, HJD_SYNC_WG>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair_totals(HjdParams P) { sync_body<2, HJD_SYNC_WG>(P); }
 
 // ---- stage 3: final entropy decode, coefficients out ------------------------------------------
 
@@ -1539,14 +1545,14 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 // ---- launch wrappers --------------------------------------------------------------------------
 
 // Dynamic LDS above 32 KB needs the function attribute raised once per (kernel, device) — not on every launch
-// (round 2 paid a hipFuncSetAttribute per launch, 36 per bench step).  `which` = 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_write.
+// (round 2 paid a hipFuncSetAttribute per launch, 36 per bench step).  `which` = 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_write, 4 k_sync_small.
 static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
 {
     // hipFuncSetAttribute is last-writer-wins, so the check, the call and the record of what was granted are ONE critical
     // section: two host threads launching the same kernel for the first time with different sizes (decoders with different
     // subsequence sizes or staging windows) must not leave the attribute below what the table says was granted.
     static std::mutex mu;
-    static uint32_t granted[4][16];
+    static uint32_t granted[5][16];
     if (bytes <= 32768) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
@@ -1563,6 +1569,9 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (mode == 0) {
         if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
+    } else if (mode == 3) {
+        if (set_dyn_lds(4, reinterpret_cast<const void *>(k_sync_small), P.lds_bytes_sync_small)) return -1;
+        hipLaunchKernelGGL(k_sync_small, dim3(nwg), dim3(HJD_SYNC_WG_SMALL / HJD_SYNC_C), P.lds_bytes_sync_small, s, P);
     } else if (mode == 1) {
         if (set_dyn_lds(1, reinterpret_cast<const void *>(k_repair), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);

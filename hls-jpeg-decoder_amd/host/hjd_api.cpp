@@ -172,7 +172,7 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
+    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
@@ -184,10 +184,15 @@ struct hjd_batch {
     // DRI (it returns at once for those the parallel path did not flag) and a gated launch of the back end, on a side stream
     // that waits for the run and that hjd_batch_finish waits for.  Nothing is allocated and no host round trip is needed.
     std::vector<uint32_t> rst_images; // device images with DRI, ascending
+    // The small synchronisation workgroups of a range run BESIDE its large ones, on a side stream of the range (forked after the
+    // unstuff stage, joined before the final pass): one kernel after the other in one stream cost a mixed batch (BASELINE
+    // config 5) the whole of the second one's latency.
+    struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, done = nullptr; };
+    std::vector<SideStream> small_side; // per range (entry 0 also serves the single-range form)
     hipStream_t seq_stream = nullptr;
     hipEvent_t seq_fork = nullptr, seq_done = nullptr;
     bool seq_pending = false;
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
     uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
@@ -474,6 +479,11 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_dca);
     (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
+    for (auto &ss : b->small_side) {
+        if (ss.st) (void)hipStreamDestroy(ss.st);
+        if (ss.fork) (void)hipEventDestroy(ss.fork);
+        if (ss.done) (void)hipEventDestroy(ss.done);
+    }
     if (b->seq_stream) (void)hipStreamDestroy(b->seq_stream);
     if (b->seq_fork) (void)hipEventDestroy(b->seq_fork);
     if (b->seq_done) (void)hipEventDestroy(b->seq_done);
@@ -511,7 +521,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->out_bytes.clear();
     b->hdr_bytes.clear();
     b->ranges.clear();
-    b->nchunks = b->nsub = b->nsyncwg = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
+    b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
     b->dirty_decodes = 0;
@@ -593,9 +603,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.sub0 = b->nsub;
         im.nsub_cap = (uint32_t)(((uint64_t)im.scan_len * 8 + S - 1) / S);
         b->nsub += im.nsub_cap;
-        im.syncwg0 = b->nsyncwg;
-        im.nsyncwg = (im.nsub_cap + Q - 1) / Q;
-        b->nsyncwg += im.nsyncwg;
+        // An image whose whole scan fits one small synchronisation workgroup (with the same warm-up allowance) gets one:
+        // k_sync_small, numbered on its own
+        im.sync_small = (K < HJD_SYNC_WG_SMALL && im.nsub_cap <= HJD_SYNC_WG_SMALL - K && !getenv("HJD_NO_SMALL_SYNC")) ? 1u : 0u;
+        if (im.sync_small) {
+            im.syncwg0 = b->nsyncwg_small;
+            im.nsyncwg = 1;
+            b->nsyncwg_small += 1;
+        } else {
+            im.syncwg0 = b->nsyncwg;
+            im.nsyncwg = (im.nsub_cap + Q - 1) / Q;
+            b->nsyncwg += im.nsyncwg;
+        }
         im.repwg0 = b->nrepwg;
         im.nrepwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
         b->nrepwg += im.nrepwg;
@@ -695,6 +714,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // k_sync: five word arrays + the u8 marks + 96 words (scratch, block tables), then one staging window per slot (the first
         // 2 x HJD_SYNC_WG words of which double as the work list)
         P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 96 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_sync_small = (P.lds_state_word_s + 5 * HJD_SYNC_WG_SMALL + HJD_SYNC_WG_SMALL / 4 + 96 + (HJD_SYNC_WG_SMALL / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
         P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
@@ -736,7 +756,19 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             return at;
         };
         off_chunk = fill(&HjdImage::chunk0, &HjdImage::nchunks);
-        off_sync = fill(&HjdImage::syncwg0, &HjdImage::nsyncwg);
+        // the two numberings of the synchronisation workgroups (HjdImage::sync_small)
+        auto fill_sync = [&](uint32_t small) {
+            const size_t at = maps.size();
+            for (int k = 0; k < b->nimg; k++) {
+                if (b->img[k].sync_small != small) continue;
+                if (maps.size() != at + b->img[k].syncwg0) return (size_t)-1;
+                maps.insert(maps.end(), b->img[k].nsyncwg, (uint32_t)k);
+            }
+            return at;
+        };
+        off_sync = fill_sync(0u);
+        const size_t off_sync_small = fill_sync(1u);
+        if (off_sync_small == (size_t)-1) return HJD_ERR_INTERNAL;
         off_rep = fill(&HjdImage::repwg0, &HjdImage::nrepwg);
         off_write = fill(&HjdImage::writewg0, &HjdImage::nwritewg);
         off_dc = fill(&HjdImage::dcchunk0, &HjdImage::ndcchunk);
@@ -759,6 +791,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         if (rcs != HJD_OK) return rcs;
         b->P.map_chunk = b->d_maps + off_chunk;
         b->P.map_syncwg = b->d_maps + off_sync;
+        b->P.map_syncwg_small = b->d_maps + off_sync_small;
         b->P.map_repwg = b->d_maps + off_rep;
         b->P.map_writewg = b->d_maps + off_write;
         b->P.map_dcchunk = b->d_maps + off_dc;
@@ -828,7 +861,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
-    P.off_chunk = P.off_syncwg = P.off_repwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
+    P.off_chunk = P.off_syncwg = P.off_syncwg_small = P.off_repwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
     {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
         uint64_t total_px = 0;
         for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
@@ -852,7 +885,21 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             r.i1 = i1;
             const HjdImage &a = b->img[i0], &z = b->img[i1 - 1];
             r.chunk0 = a.chunk0;       r.nchunk = z.chunk0 + z.nchunks - a.chunk0;
-            r.syncwg0 = a.syncwg0;     r.nsyncwg = z.syncwg0 + z.nsyncwg - a.syncwg0;
+            {   // synchronisation workgroups of the range, per numbering (images of one kind are numbered in image order)
+                bool have_big = false, have_small = false;
+                for (int q = i0; q < i1; q++) {
+                    const HjdImage &im = b->img[q];
+                    if (im.sync_small) {
+                        if (!have_small) r.ssyncwg0 = im.syncwg0;
+                        have_small = true;
+                        r.nssyncwg = im.syncwg0 + im.nsyncwg - r.ssyncwg0;
+                    } else {
+                        if (!have_big) r.syncwg0 = im.syncwg0;
+                        have_big = true;
+                        r.nsyncwg = im.syncwg0 + im.nsyncwg - r.syncwg0;
+                    }
+                }
+            }
             r.repwg0 = a.repwg0;       r.nrepwg = z.repwg0 + z.nrepwg - a.repwg0;
             r.writewg0 = a.writewg0;   r.nwritewg = z.writewg0 + z.nwritewg - a.writewg0;
             r.dc0 = a.dcchunk0;        r.ndc = z.dcchunk0 + z.ndcchunk - a.dcchunk0;
@@ -866,6 +913,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 }
             b->ranges.push_back(r);
             i0 = i1;
+        }
+        if (b->nsyncwg_small && b->nsyncwg) {
+            while (b->small_side.size() < b->ranges.size()) {
+                hjd_batch::SideStream ss;
+                HIPCHK(hipStreamCreateWithFlags(&ss.st, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
+                b->small_side.push_back(ss);
+            }
         }
         if (!b->rst_images.empty() && !b->seq_stream) {
             HIPCHK(hipStreamCreateWithFlags(&b->seq_stream, hipStreamNonBlocking));
@@ -1040,11 +1096,12 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
 // the kernel sequence for one range of images; names != nullptr records an event before each stage
 static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s, bool from_resync, int *nstage,
                          const char **names, hipEvent_t *evs, hipEvent_t wait_before_sync = nullptr,
-                         hipEvent_t record_stagger = nullptr, int stagger_after = 0)
+                         hipEvent_t record_stagger = nullptr, int stagger_after = 0, size_t side = 0)
 {
     HjdParams P = b->P;
     P.off_chunk = r.chunk0;
     P.off_syncwg = r.syncwg0;
+    P.off_syncwg_small = r.ssyncwg0;
     P.off_repwg = r.repwg0;
     P.off_writewg = r.writewg0;
     P.off_img = (uint32_t)r.i0;
@@ -1085,7 +1142,19 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
             conc_record = d->conc_ev[k & 15];
         }
         if ((rc = mark("huff_sync"))) return rc;
+        // the images with a small workgroup of their own: beside the large ones when the range holds both kinds
+        hjd_batch::SideStream *ss = (r.nssyncwg && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
+        if (ss) {
+            if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->st, ss->fork, 0) != hipSuccess) return HJD_ERR_INTERNAL;
+            if (hjd_launch_sync(P, r.nssyncwg, 3, ss->st)) return HJD_ERR_INTERNAL;
+            if (hipEventRecord(ss->done, ss->st) != hipSuccess) return HJD_ERR_INTERNAL;
+        }
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        if (ss) {
+            if (hipStreamWaitEvent(s, ss->done, 0) != hipSuccess) return HJD_ERR_INTERNAL;
+        } else if (hjd_launch_sync(P, r.nssyncwg, 3, s)) {
+            return HJD_ERR_INTERNAL;
+        }
         if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (record_stagger && stagger_after == 1 && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (nrep > 0 && (rc = mark("huff_repair"))) return rc;
@@ -1155,6 +1224,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.i1 = b->nimg;
         all.nchunk = b->nchunks;
         all.nsyncwg = b->nsyncwg;
+        all.nssyncwg = b->nsyncwg_small;
         all.nrepwg = b->nrepwg;
         all.nwritewg = b->nwritewg;
         all.ndc = b->ndcchunks;
@@ -1175,7 +1245,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         hipStream_t sk = k ? b->istreams[k] : s;
         if (k) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0));
         int rc = range_enqueue(b, b->ranges[k], sk, from_resync, nullptr, nullptr, nullptr,
-                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger);
+                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, k);
         if (rc) return rc;
         if (k) HIPCHK(hipEventRecord(b->join_ev[k], sk));
     }

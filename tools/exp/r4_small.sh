@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; cd $R; T=${TAG:-r4sm}
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/${T}_tests.log 2>&1; tail -3 $O/${T}_tests.log
+timeout -k 10 200 python3 tools/small_images.py 2>&1 | grep -v amdgpu > $O/${T}_small.txt
+timeout -k 10 200 python3 tools/config5_bench.py > $O/${T}_config5.json 2> $O/${T}_config5.err
+cat $O/${T}_small.txt; python3 -c "
+import json
+d=json.loads(open('$O/${T}_config5.json').read().strip().splitlines()[-1]); print('config5', d['value'], d['ms_per_step'])"
