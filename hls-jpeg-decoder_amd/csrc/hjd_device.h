@@ -151,5 +151,8 @@ struct HjdImageState {
 // synchronisation record of one subsequence (substate[]): x = end state bit position (>= end of the
 // subsequence), y = end state z | m << 8, z / w = the start state this record was computed from
 #define HJD_REC_PAD 0xFFFFFFFFu
-#define HJD_REC_RUN 8 // every k_write lane's run of records is padded to a multiple: a lane stores 32 aligned bytes at a time — a whole
+#ifndef HJD_REC_RUN
+#define HJD_REC_RUN 8
+#endif
+// every k_write lane's run of records is padded to a multiple: a lane stores 32 aligned bytes at a time — a whole
                       // sector (16-byte bursts, round 2, wrote every sector of the record array twice)

@@ -136,6 +136,14 @@ struct RestartCtx {
 // ring[k * HJD_WRITE_WG]): every lane's run of records starts at a multiple of HJD_REC_RUN, so a full burst is two aligned
 // global_store_dwordx4 back to back, one 32-byte sector.  (Until round 3 the burst was a shift register of eight VGPRs: fourteen
 // v_mov per loop iteration around the record branch, whether the iteration produced a record or not.)
+// 16 bytes of records.  (Streamed with non-temporal stores — tried this round, to keep the record array out of the L2 — k_write
+// took 0.28 ms instead of 0.15: a lane's 16-byte pieces then leave one by one.)
+typedef uint32_t hjd_rec4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_records(uint32_t *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    *reinterpret_cast<hjd_rec4 *>(dst) = (hjd_rec4){a, b, c, d};
+}
+
 struct WriteCtx {
     uint32_t *ring;
     uint32_t *rec;
@@ -342,13 +350,15 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 flags |= HJD_FLAG_OVERRUN;
                 w = HJD_REC_PAD;
             }
-            static_assert(HJD_REC_RUN == 8, "two 16-byte halves per burst");
-            W.ring[(nrec & 7u) * HJD_WRITE_WG] = w;
-            if ((nrec & 7u) == 7u) { // a burst of eight is complete: one 32-byte sector
+            static_assert(HJD_REC_RUN % 4 == 0 && (HJD_REC_RUN & (HJD_REC_RUN - 1)) == 0, "16-byte pieces");
+            W.ring[(nrec & (HJD_REC_RUN - 1u)) * HJD_WRITE_WG] = w;
+            if ((nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u) { // a burst is complete: whole, aligned sectors
                 if (nrec < W.rec_cap) {
-                    uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - 7u));
-                    dst[0] = make_uint4(W.ring[0], W.ring[HJD_WRITE_WG], W.ring[2 * HJD_WRITE_WG], W.ring[3 * HJD_WRITE_WG]);
-                    dst[1] = make_uint4(W.ring[4 * HJD_WRITE_WG], W.ring[5 * HJD_WRITE_WG], W.ring[6 * HJD_WRITE_WG], W.ring[7 * HJD_WRITE_WG]);
+                    uint32_t *dst = W.rec + (nrec - (HJD_REC_RUN - 1u));
+#pragma unroll
+                    for (uint32_t q = 0; q < HJD_REC_RUN / 4u; q++)
+                        store_records(dst + 4u * q, W.ring[(4u * q) * HJD_WRITE_WG], W.ring[(4u * q + 1u) * HJD_WRITE_WG],
+                                      W.ring[(4u * q + 2u) * HJD_WRITE_WG], W.ring[(4u * q + 3u) * HJD_WRITE_WG]);
                 } else {
                     flags |= HJD_FLAG_OVERRUN;
                 }
@@ -1530,9 +1540,11 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
         for (uint32_t q = k; q < HJD_REC_RUN; q++) W.ring[q * HJD_WRITE_WG] = HJD_REC_PAD;
         if (nrec + HJD_REC_RUN - k <= im.rec_cap) {
-            uint4 *dst = reinterpret_cast<uint4 *>(W.rec + (nrec - k));
-            dst[0] = make_uint4(W.ring[0], W.ring[HJD_WRITE_WG], W.ring[2 * HJD_WRITE_WG], W.ring[3 * HJD_WRITE_WG]);
-            dst[1] = make_uint4(W.ring[4 * HJD_WRITE_WG], W.ring[5 * HJD_WRITE_WG], W.ring[6 * HJD_WRITE_WG], W.ring[7 * HJD_WRITE_WG]);
+            uint32_t *dst = W.rec + (nrec - k);
+#pragma unroll
+            for (uint32_t q = 0; q < HJD_REC_RUN / 4u; q++)
+                store_records(dst + 4u * q, W.ring[(4u * q) * HJD_WRITE_WG], W.ring[(4u * q + 1u) * HJD_WRITE_WG], W.ring[(4u * q + 2u) * HJD_WRITE_WG],
+                              W.ring[(4u * q + 3u) * HJD_WRITE_WG]);
         } else {
             flags |= HJD_FLAG_OVERRUN;
         }
