@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         const uint32_t lg = (uint32_t)__ffs((int)G) - 1u; // G is a power of two
         for (uint32_t idx = tid; idx < G * (wps + 2u); idx += HJD_WRITE_WG) {
             const uint32_t k = idx >> lg, r = idx & (G - 1u);
-            if (r < nrows) s_rows[k * stride + r] = row_base(wbase, i0 + r, lw)[(size_t)k * 64u];
+            if (r < nrows) s_rows[k * stride + r] = row_base(wbase, i0 + r, lw)[(size_t)k * 64u]; // (non-temporal loads here: no difference)
         }
     }
 

@@ -40,6 +40,7 @@ struct HjdParams {
     uint32_t conformant;       // hjd_options.conformant: selects the conformant instantiation of the back end
     uint32_t gate_emulated;    // k_idct_color: 1 = only images the sequential emulation has just decoded (HjdImageState::emulated)
     const uint32_t *rst_list;  // device images that carry DRI, ascending (the sequential emulation's candidates)
+    const uint32_t *rst_groups; // the back-end workgroups (batch-global numbers) of those images: the grid of the gated launch
     uint32_t subseq_bits;      // power of two, 64..4096
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup

@@ -239,10 +239,12 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     __shared__ uint8_t s_order[MAXGB];    // blocks in descending order of their term count
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t bid = blockIdx.x + P.off_group;
+    // second launch, after the sequential emulation (gate_emulated): its grid is the list of the groups of the images that carry DRI,
+    // and of those only the images the emulation has just decoded go on
+    const uint32_t bid = P.gate_emulated ? P.rst_groups[blockIdx.x] : blockIdx.x + P.off_group;
     const uint2 gm = P.map_group[bid];
     const int ii = (int)gm.x;
-    if (P.gate_emulated && !P.st[ii].emulated) return; // second launch, after the sequential emulation: its images only
+    if (P.gate_emulated && !P.st[ii].emulated) return;
     const HjdImage &im = P.img[ii];
     const uint32_t lg = bid - im.group0;
     const uint32_t mrow = lg / im.groups_per_row, gx = lg % im.groups_per_row;
@@ -309,12 +311,8 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
         const uint32_t r1 = min(s_range[1], r0 + HJD_REC_RUN * 63u * KB + HJD_REC_RUN);
         const uint32_t b0 = (uint32_t)(gm.y - im.blk_off);
         for (uint32_t t = (r0 & ~3u) + tid * 4u; t < r1; t += 1024u) {
-#ifdef HJD_REC_NT_LOAD
             typedef uint32_t rec4_t __attribute__((ext_vector_type(4)));
-            const rec4_t q = __builtin_nontemporal_load(reinterpret_cast<const rec4_t *>(rec + t));
-#else
-            const uint4 q = *reinterpret_cast<const uint4 *>(rec + t);
-#endif
+            const rec4_t q = __builtin_nontemporal_load(reinterpret_cast<const rec4_t *>(rec + t)); // read once: not worth a place in the L2 (+2 %)
             const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {

@@ -184,6 +184,7 @@ struct hjd_batch {
     // DRI (it returns at once for those the parallel path did not flag) and a gated launch of the back end, on a side stream
     // that waits for the run and that hjd_batch_finish waits for.  Nothing is allocated and no host round trip is needed.
     std::vector<uint32_t> rst_images; // device images with DRI, ascending
+    uint32_t nrst_groups = 0;         // back-end workgroups of those images
     // The small synchronisation workgroups of a range run BESIDE its large ones, on a side stream of the range (forked after the
     // unstuff stage, joined before the final pass): one kernel after the other in one stream cost a mixed batch (BASELINE
     // config 5) the whole of the second one's latency.
@@ -776,6 +777,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             return HJD_ERR_INTERNAL;
         const size_t off_rst = maps.size(); // the sequential emulation's candidates
         maps.insert(maps.end(), b->rst_images.begin(), b->rst_images.end());
+        const size_t off_rstg = maps.size(); // ... and their back-end workgroups: the gated second launch runs exactly these
+        for (uint32_t q : b->rst_images)
+            for (uint32_t g = 0; g < b->img[q].ngroups; g++) maps.push_back(b->img[q].group0 + g);
+        b->nrst_groups = (uint32_t)(maps.size() - off_rstg);
         if (maps.size() & 1) maps.push_back(0); // the uint2 table that follows is 8-byte aligned
         off_group = maps.size();
         for (int k = 0; k < b->nimg; k++) {
@@ -797,6 +802,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->P.map_dcchunk = b->d_maps + off_dc;
         b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
         b->P.rst_list = b->d_maps + off_rst;
+        b->P.rst_groups = b->d_maps + off_rstg;
     }
     {   // stage everything that goes up in ONE pinned buffer: [scan bytes | image descriptors | tables | maps]
         const size_t o_img = align_up(raw_cur, 256), o_tab = align_up(o_img + sizeof(HjdImage) * b->nimg, 256);
@@ -1186,13 +1192,11 @@ static int emulation_enqueue(hjd_batch *b, hipStream_t s)
     HIPCHK(hipEventRecord(b->seq_fork, s));
     HIPCHK(hipStreamWaitEvent(b->seq_stream, b->seq_fork, 0));
     if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream)) return HJD_ERR_INTERNAL;
-    {   // the back end again, ONE launch over the groups from the first to the last candidate: the workgroups of every image the
-        // emulation has not touched return at once
+    {   // the back end again, over the candidates' workgroups only (round 3 launched the whole span from the first to the last
+        // candidate: a batch with restart streams at both ends ran a million workgroups that returned at once)
         HjdParams P = b->P;
         P.gate_emulated = 1u;
-        const HjdImage &a = b->img[b->rst_images.front()], &z = b->img[b->rst_images.back()];
-        P.off_group = a.group0;
-        if (hjd_launch_idct_color(P, z.group0 + z.ngroups - a.group0, b->seq_stream)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_idct_color(P, b->nrst_groups, b->seq_stream)) return HJD_ERR_INTERNAL;
     }
     HIPCHK(hipEventRecord(b->seq_done, b->seq_stream));
     b->seq_pending = true;
