@@ -47,6 +47,7 @@ __constant__ float c_cos_true[64] = {
     1.0f, -0.98078528f, 0.92387953f, -0.83146961f, 0.70710678f, -0.55557023f, 0.38268343f, -0.19509032f};
 
 #define MAXGB (HJD_GROUP_MCUS * 6) // blocks per workgroup
+#define HJD_PIX_ROW 132            // bytes between the 8x8 tiles of two blocks in LDS: a tile takes the place of its block's coefficients
 
 // ---- colour ------------------------------------------------------------------------------------
 // ConvertYCrCbtoRGB as called at loadjpg.cpp:918 (:867-880): R = (int)(Y + 1.402 (Cr-128)),
@@ -123,7 +124,7 @@ __device__ __forceinline__ void rgb12(uint32_t y4, const ChromaTerms &t0, const 
 // code; the output pointer is stepped by the row stride instead of being rebuilt, and the 12-byte store's
 // alignment is decided once per thread whenever the stride is a multiple of 4.
 template <bool BMP, bool CONF, uint32_t HF>
-__device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
+__device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[HJD_PIX_ROW], uint32_t tid,
                                                uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
 {
     const uint32_t W = im.width, H = im.height, vf = im.vf, nb = im.nb, nby = im.nby;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void color_store_hf(const HjdImage &im, uint8_t *__re
 }
 
 template <bool BMP, bool CONF>
-__device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[72], uint32_t tid,
+__device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restrict__ out, const uint8_t (*s_pix)[HJD_PIX_ROW], uint32_t tid,
                                             uint32_t mrow, uint32_t mcu_first, uint32_t K, uint32_t lg)
 {
     if (im.hf == 2) color_store_hf<BMP, CONF, 2u>(im, out, s_pix, tid, mrow, mcu_first, K, lg);
@@ -227,10 +228,14 @@ __device__ __forceinline__ void color_store(const HjdImage &im, uint8_t *__restr
 template <bool CONF>
 __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
 {
-    __shared__ int16_t s_coef[MAXGB][66]; // dequantised, index = slot u*8+v (u = horizontal frequency); +2 pad: bank spread
+    __shared__ __attribute__((aligned(8))) int16_t s_coef[MAXGB][66]; // dequantised, index = slot u*8+v (u = horizontal frequency); +2 pad: bank spread
     __shared__ uint32_t s_mask[MAXGB][2]; // bit = slot holds a coefficient (lo: slots 0-31, hi: 32-63)
     __shared__ uint8_t s_comp[MAXGB + 32]; // component (0 Y, 1 Cb, 2 Cr) of every block of the group
-    __shared__ __attribute__((aligned(8))) uint8_t s_pix[MAXGB][72]; // decoded 8x8 tiles, row-major; +8 pad: bank spread
+    // The decoded 8x8 tile of a block (row-major, 64 bytes) is written over the block's coefficients: only the block's own
+    // 4-lane team reads them, and it has read them all when it stores the first pixel.  (With an array of their own the tiles
+    // took 6.9 KB more: seven workgroups per CU instead of eight.)
+    static_assert(sizeof(int16_t) * 66 == HJD_PIX_ROW, "one tile per coefficient row");
+    uint8_t (*s_pix)[HJD_PIX_ROW] = reinterpret_cast<uint8_t (*)[HJD_PIX_ROW]>(&s_coef[0][0]);
     __shared__ __attribute__((aligned(16))) float s_cos[64]; // [u][x] = COS[x][u]; read as [v][y] = COS[y][v] too
     __shared__ float s_kk[64];            // C(u)*C(v) by slot
     __shared__ __attribute__((aligned(4))) uint8_t s_qt[3][64]; // by slot
