@@ -45,6 +45,7 @@
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
+#define HJD_ENT_CAP 2048u      // block entries a final-pass workgroup collects in LDS before it writes them out together
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 

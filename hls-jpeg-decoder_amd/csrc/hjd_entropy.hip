@@ -154,16 +154,23 @@ struct WriteCtx {
     uint32_t bfirst;        // first record of the block in progress, or ~0 when the block began in an earlier span
     uint32_t bdc;
     uint32_t tag;           // block bits of a record: (block & 127) << 22
+    uint32_t *ent;          // LDS: the workgroup's block entries in the making (HJD_ENT_CAP words, all ones = not written here)
+    uint32_t b0, r0;        // the workgroup's first block / first record
 };
 
-// The entry of block b = (first record, DC difference), written once and whole — one 8-byte store — by the lane that decoded
-// the block's DC symbol (bfirst != ~0), when the block ends or the lane's span does.  (Rounds 2-3 wrote 16 bytes per block,
-// with the mask of the slots the block's records fill, plus the DC difference once more into a 2-byte array for the DC
-// prediction kernels: k_write wrote 1.8 times its useful bytes, most of the excess in those lone 2- and 16-byte stores.  The
-// back end builds the masks from the records themselves — it touches every record anyway.)
+// The entry of block b = (first record, DC difference), made by the lane that decoded the block's DC symbol (bfirst != ~0), when
+// the block ends or the lane's span does.  A workgroup's blocks are consecutive, so the entries wait in LDS — 4 bytes: first
+// record relative to the workgroup's first | DC difference << 16 — and leave together at the end, whole lines of them (k_write).
+// (Rounds 2-3 stored 16 bytes per block, with the mask of the slots the block's records fill, plus the DC difference once more
+// into a 2-byte array for the DC prediction kernels; every such lone store cost a 32-byte write: k_write wrote 1.8 times its
+// useful bytes.  The back end builds the masks from the records themselves — it touches every record anyway.)
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
-    if (W.bfirst != 0xFFFFFFFFu) W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu);
+    if (W.bfirst != 0xFFFFFFFFu) {
+        const uint32_t idx = b - W.b0, rel = W.bfirst - W.r0;
+        if (idx < HJD_ENT_CAP && rel < 0xFFFFu) W.ent[idx] = rel | (W.bdc << 16);
+        else W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu); // more blocks or records than the staging holds: straight out
+    }
     W.bfirst = 0xFFFFFFFFu;
 }
 
@@ -1427,7 +1434,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_w + 48);
     uint32_t *s_ring = s_w + 64;                        // [HJD_REC_RUN][HJD_WRITE_WG]: the lanes' bursts in the making
-    uint32_t *s_rows = s_ring + HJD_REC_RUN * HJD_WRITE_WG;
+    uint32_t *s_ent = s_ring + HJD_REC_RUN * HJD_WRITE_WG; // [HJD_ENT_CAP]: block entries in the making
+    uint32_t *s_rows = s_ent + HJD_ENT_CAP;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits, wps = S >> 5, nph = wps / P.phase_words;
@@ -1439,6 +1447,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     if (wg * HJD_WRITE_WG >= nsub * nu) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
+    for (uint32_t k = tid; k < HJD_ENT_CAP; k += HJD_WRITE_WG) s_ent[k] = 0xFFFFFFFFu;
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
     {   // the workgroup's rows: word k of row i0 + r -> s_rows[k * stride + r] (rows past the scan's end stay unread)
         const uint32_t i0 = wg * G, nrows = min(G, nsub - i0), lw = P.log2_words;
@@ -1512,7 +1521,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         }
     }
 
-    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks, s_slot, 0xFFFFFFFFu, 0u, 0u};
+    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks, s_slot, 0xFFFFFFFFu, 0u, 0u, s_ent, base_b, base_r};
     W.tag = (blk & 127u) << 22; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
     const uint32_t row_bit0 = i * S;
@@ -1552,6 +1561,17 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     // one atomic per wave
     for (int d = 32; d >= 1; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
     if (lane == 0 && flags) atomicOr(&P.st[ii].flags, flags);
+    // the workgroup's block entries: blocks [base_b, base_b + tot_b] (the last one in progress at the workgroup's end), those whose DC
+    // symbol lies in this workgroup; 8 bytes each, consecutive lanes consecutive blocks
+    __syncthreads();
+    {
+        uint2 *blk_out = P.blk + im.blk_off + base_b;
+        const uint32_t n = min(tot_b + 1u, HJD_ENT_CAP);
+        for (uint32_t k = tid; k < n; k += HJD_WRITE_WG) {
+            const uint32_t v = s_ent[k];
+            if (v != 0xFFFFFFFFu) blk_out[k] = make_uint2(base_r + (v & 0xFFFFu), v >> 16);
+        }
+    }
 }
 
 // ---- launch wrappers --------------------------------------------------------------------------

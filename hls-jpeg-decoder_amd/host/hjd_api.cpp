@@ -553,7 +553,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     const uint32_t nph = (S / 32) / wpp; // windows per subsequence
     uint32_t wwn = d->write_windows;     // windows per k_write lane
     if (wwn > nph) wwn = nph;
-    while (wwn > 1 && (size_t)(S / 32 + 2) * (HJD_WRITE_WG / (nph / wwn) + 1) * 4 > (96u << 10)) wwn /= 2; // k_write keeps its rows in LDS
+    while (wwn > 1 && (size_t)(S / 32 + 2) * (HJD_WRITE_WG / (nph / wwn) + 1) * 4 > (88u << 10)) wwn /= 2; // k_write keeps its rows in LDS
     const uint32_t nu = nph / wwn;       // k_write lanes per subsequence
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
@@ -717,7 +717,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 96 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
         P.lds_bytes_sync_small = (P.lds_state_word_s + 5 * HJD_SYNC_WG_SMALL + HJD_SYNC_WG_SMALL / 4 + 96 + (HJD_SYNC_WG_SMALL / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
-        P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
+        P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + HJD_ENT_CAP + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
 
