@@ -870,7 +870,13 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     static_assert(MODE == 0 || !SMALL, "the repair kernels have one size");
-    const uint32_t bid = blockIdx.x + (MODE == 0 ? (SMALL ? P.off_syncwg_small : P.off_syncwg) : P.off_repwg);
+    // Sibling workgroups (small batches only, HjdParams::tk_n): the grid holds tk_n + 1 workgroups per synchronisation workgroup,
+    // the siblings first.  A sibling decodes round 0 over again with another block-in-MCU label from the second staging window on
+    // and leaves its checkpoints in a slab of its own; see the refinement rounds.
+    const uint32_t TK = (MODE == 0 && !SMALL) ? P.tk_n : 0u;
+    const uint32_t sib = TK ? TK - blockIdx.x / P.tk_nwg : 0u; // 0 = the workgroup proper
+    const uint32_t bix = TK ? blockIdx.x % P.tk_nwg : blockIdx.x;
+    const uint32_t bid = bix + (MODE == 0 ? (SMALL ? P.off_syncwg_small : P.off_syncwg) : P.off_repwg);
     const int ii = (int)(MODE == 0 ? (SMALL ? P.map_syncwg_small[bid] : P.map_syncwg[bid]) : P.map_repwg[bid]);
     static_assert(HJD_SYNC_WG % HJD_WRITE_WG == 0, "a repair workgroup covers whole final-pass workgroups");
     const HjdImage &im = P.img[ii];
@@ -942,9 +948,14 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         return slot >= nwarm ? ck_canon + (size_t)ph * im.nsub_cap + slot : ck_scr + ph * K + slot;
     };
 
+    // sibling t's checkpoints of the subsequences this workgroup owns (same layout as the canonical ones, in slab t)
+    auto tkck = [&](uint32_t t, uint32_t ph, uint32_t slot) -> uint2 * {
+        return P.tk_ckpt + (size_t)t * P.tk_stride + (size_t)im.sub0 * nph + row0 + (size_t)ph * im.nsub_cap + slot;
+    };
+
     uint32_t ext_p = row0 * S, ext_zm = 0; // start state offered to slot 0 from outside the workgroup
     // HJD_SYNC_PROF (diagnostics, tools/sync_profile.py): shader-clock stamps of this workgroup's stages
-    unsigned long long *dbg = (MODE == 0 && !SMALL && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
+    unsigned long long *dbg = (MODE == 0 && !SMALL && sib == 0u && P.dbg) ? P.dbg + (size_t)bid * 32u : nullptr;
     uint32_t dbg_k = 0;
     auto stamp = [&](unsigned long long extra) {
         if (dbg && tid == 0 && dbg_k < 30u) {
@@ -956,6 +967,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     uint32_t ndec_total = 0, nphase_items = 0;
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) s_mark[sl[c]] = 0;
+    if (tid == 0) s_wc[33] = 0u;
 
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
@@ -999,12 +1011,35 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) phs[c] = ph;
             decode_windows<(int)C>(E, valid, row, phs, p, z, m, nblk, nrec, mk);
+            if (sib != 0u) {
+                // A sibling: the same decode as the workgroup proper through the first window — after it a guessed decode has
+                // nearly always found the code boundaries, and what it still has wrong is the block's place in the MCU — then on
+                // with ANOTHER label (of the same table class first: loadjpg.cpp:945-997 gives the luma blocks of an MCU one
+                // pair of tables, Cb and Cr usually another).  One of the labels is the true one.
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    if (ph == 0u) {
+                        const uint32_t nby = im.nby, nb = im.nb, s1 = sib, mm = m[c];
+                        if (mm < nby) m[c] = s1 < nby ? (mm + s1) % nby : min(nby + (s1 - nby), nb - 1u);
+                        else m[c] = s1 == 1u ? (mm == nby ? nby + 1u : nby) : (s1 - 2u) % nby;
+                    } else if (owned[c]) {
+                        *tkck(sib - 1u, ph, sl[c]) = make_uint2(p[c], z[c] | (m[c] << 6) | (nblk[c] << 9) | (nrec[c] << 20));
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) {
                 if (valid[c]) *ck(ph, sl[c]) = make_uint2(p[c], z[c] | (m[c] << 6) | (nblk[c] << 9) | (nrec[c] << 20));
                 tb[c] += nblk[c];
                 tr[c] += nrec[c];
             }
+        }
+        if (sib != 0u) { // the checkpoints are out: tell the workgroup proper (release, device scope: it may run on another XCD)
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&P.tk_flags[(size_t)bid * TK + (sib - 1u)], P.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) {
@@ -1045,6 +1080,23 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     stamp(2); // this wave's round 0 done
     __syncthreads();
     stamp(3); // everybody's
+    // The siblings' checkpoints: waited for a bounded time (they started before this workgroup and do the same work); one that
+    // has not reported is simply not used — its checkpoints are hints, never results.
+    uint32_t tk_ok = 0u;
+    if (TK) {
+        if (tid < TK) {
+            bool ok = false;
+            for (uint32_t spin = 0; spin < 4000u && !ok; spin++) {
+                ok = __hip_atomic_load(&P.tk_flags[(size_t)bid * TK + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == P.epoch;
+                if (!ok) __builtin_amdgcn_s_sleep(16);
+            }
+            if (ok) atomicOr(&s_wc[33], 1u << tid);
+        }
+        __syncthreads();
+        tk_ok = s_wc[33];
+        __syncthreads();
+    }
+    stamp(4);
 
     // Uniform regions.  Every MCU of a uniform image is the same few bits (4:2:0 with the standard tables: 32; with tables
     // optimised for the image 12 or less), so the stream is periodic, and on a periodic stream a guessed decode either falls into
@@ -1268,12 +1320,17 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             for (int c = 0; c < NC; c++) wmk[c] = live[c] ? s_mk0[slot[c]] : 0u; // the walk's marker scan: never behind the state's position, which only grows
             if (!__any(anylive)) return; // waves without work go straight to the barrier
             for (uint32_t step = 0; __any(anylive) && step < 65536u; step++) {
-                uint2 old[NC];
+                uint2 old[NC], sbl[NC][3];
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     old[c] = make_uint2(0xFFFFFFFFu, 0u);
                     if (live[c]) old[c] = *ck(ph[c], slot[c]); // arrives while the window is decoded
                     wrow[c] = row0 + slot[c];
+#pragma unroll
+                    for (uint32_t t = 0; t < 3u; t++) { // the siblings' states at this window's end (owned subsequences, from the second window on)
+                        sbl[c][t] = make_uint2(0xFFFFFFFFu, 0u);
+                        if (live[c] && ((tk_ok >> t) & 1u) && ph[c] != 0u && slot[c] >= nwarm) sbl[c][t] = *tkck(t, ph[c], slot[c]);
+                    }
                 }
                 decode_windows<NC>(E, live, wrow, ph, p, z, m, nblk, nrec, wmk);
                 steps_done++;
@@ -1287,11 +1344,44 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     const bool met = p[c] == old[c].x && st9 == (old[c].y & 511u);
                     co[c] += ((old[c].y >> 9) & 2047u) | ((old[c].y >> 20) << 16);
                     *ck(ph[c], slot[c]) = make_uint2(p[c], st9 | (nblk[c] << 9) | (nrec[c] << 20));
+                    int sibmet = -1; // in step with a sibling's decode instead?
+                    if (!met && tk_ok) {
+#pragma unroll
+                        for (int t = 2; t >= 0; t--)
+                            if (p[c] == sbl[c][t].x && st9 == (sbl[c][t].y & 511u)) sibmet = t;
+                    }
                     if (met) {
                         // in step with the previous decode from here on: its end state stands, its totals change by the
                         // difference over the windows walked (field-wise: no field of the sum can borrow)
                         s_cnt[slot[c]] = s_cnt[slot[c]] + cn[c] - co[c];
                         live[c] = false;
+                    } else if (sibmet >= 0 && ph[c] + 1u < nph) {
+                        // The rest of the subsequence is the sibling's: its checkpoints become the subsequence's own, its end state
+                        // the subsequence's.  If that is not the state the next subsequence was decoded from, the walk goes on there.
+                        uint2 last = make_uint2(0u, 0u);
+                        for (uint32_t w = ph[c] + 1u; w < nph; w++) {
+                            last = *tkck((uint32_t)sibmet, w, slot[c]);
+                            *ck(w, slot[c]) = last;
+                            cn[c] += ((last.y >> 9) & 2047u) | ((last.y >> 20) << 16);
+                        }
+                        p[c] = last.x;
+                        z[c] = last.y & 63u;
+                        m[c] = (last.y >> 6) & 7u;
+                        const uint32_t ezm = z[c] | (m[c] << 8);
+                        s_ep[slot[c]] = p[c];
+                        s_ezm[slot[c]] = (uint16_t)ezm;
+                        s_cnt[slot[c]] = cn[c];
+                        const uint32_t nx = slot[c] + 1u;
+                        live[c] = nx < NS && row0 + nx < lim && s_mark[nx] != rounds + 1u && (s_up[nx] != p[c] || (uint32_t)s_uzm[nx] != ezm);
+                        if (live[c]) {
+                            s_mark[nx] = (uint8_t)(rounds + 1u);
+                            s_up[nx] = p[c];
+                            s_uzm[nx] = (uint16_t)ezm;
+                            slot[c] = nx;
+                            ph[c] = 0u;
+                            cn[c] = 0u;
+                            co[c] = 0u;
+                        }
                     } else if (ph[c] + 1u < nph) {
                         ph[c]++;
                     } else { // end of the subsequence with a state of its own
@@ -1600,7 +1690,9 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (!nwg) return 0;
     if (mode == 0) {
         if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
-        hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
+        HjdParams Q = P;
+        Q.tk_nwg = nwg; // the grid: tk_n sibling workgroups per synchronisation workgroup first, then the workgroups proper
+        hipLaunchKernelGGL(k_sync, dim3(nwg * (P.tk_n + 1u)), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, Q);
     } else if (mode == 3) {
         if (set_dyn_lds(4, reinterpret_cast<const void *>(k_sync_small), P.lds_bytes_sync_small)) return -1;
         hipLaunchKernelGGL(k_sync_small, dim3(nwg), dim3(HJD_SYNC_WG_SMALL / HJD_SYNC_C), P.lds_bytes_sync_small, s, P);

@@ -23,6 +23,13 @@ struct HjdParams {
                                // blocks inside the window << 9 | records inside it << 20; after ck_scratch entries: k_sync's
                                // private copies for its warm-up slots, per workgroup [window][slot < sync_overlap]
     uint64_t ck_scratch;       // first entry of that scratch area
+    // Sibling trajectories (small batches: the chip has room for several decodes of every subsequence).  tk_n sibling workgroups
+    // per synchronisation workgroup repeat round 0 with another block-in-MCU label from the second staging window on; their
+    // checkpoints (slab t at tk_ckpt + t * tk_stride, canonical layout) are further states a refinement walk may fall into step with.
+    uint2 *tk_ckpt;
+    uint64_t tk_stride;
+    uint32_t *tk_flags;        // [synchronisation workgroup][sibling]: the run (epoch) whose checkpoints are complete
+    uint32_t tk_n, tk_nwg, epoch;
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
     uint2 *blk;                // per block: first record index, DC difference as decoded (k_write)

@@ -210,6 +210,9 @@ struct hjd_batch {
     uint32_t *d_subcnt = nullptr;
     uint32_t *d_submk = nullptr; // restart streams: per subsequence, index of the first marker past its first bit (k_sync -> k_write, repair)
     uint2 *d_ckpt = nullptr;
+    uint2 *d_tkck = nullptr;        // sibling trajectories' checkpoints (small batches)
+    uint32_t *d_tkflags = nullptr;
+    uint32_t epoch = 0;             // run counter: what a sibling workgroup's flag must show
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
     uint2 *d_blk = nullptr;
@@ -473,6 +476,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_subcnt);
     (void)hipFree(b->d_submk);
     (void)hipFree(b->d_ckpt);
+    (void)hipFree(b->d_tkck);
+    (void)hipFree(b->d_tkflags);
     (void)hipFree(b->d_dbg);
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
@@ -738,6 +743,24 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_submk, sizeof(uint32_t) * b->nsub));
     P.ck_scratch = (uint64_t)b->nsub * nph; // canonical entries first, then k_sync's private ones for its warm-up slots
     need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * ((size_t)b->nsub * nph + (size_t)b->nsyncwg * nph * K + 1)));
+    {   // Sibling trajectories (HjdParams::tk_n): when the whole batch is a few dozen synchronisation workgroups the chip sits idle
+        // under k_sync's latency chain — three further decodes of every subsequence cost no time then, and a refinement walk falls
+        // into step with one of four trajectories instead of one.  HJD_SIBLINGS=0..3: tuning / test knob.
+        uint32_t tk = (b->nsyncwg != 0 && b->nsyncwg * 4u <= 128u) ? 3u : 0u;
+        if (const char *e = getenv("HJD_SIBLINGS")) tk = (uint32_t)(atoi(e) < 0 ? 0 : (atoi(e) > 3 ? 3 : atoi(e)));
+        if (b->nsyncwg == 0) tk = 0;
+        P.tk_n = tk;
+        P.tk_stride = (uint64_t)b->nsub * nph;
+        P.tk_nwg = 0;
+        if (tk) {
+            need(slab_reserve(b, b->d_tkck, sizeof(uint2) * ((size_t)b->nsub * nph * tk + 1)));
+            const size_t before = b->cap[(const void *)&b->d_tkflags];
+            need(slab_reserve(b, b->d_tkflags, sizeof(uint32_t) * ((size_t)b->nsyncwg * tk + 1)));
+            if (rcs == HJD_OK && b->cap[(const void *)&b->d_tkflags] != before) { // a fresh slab: no flag may look like a run's epoch
+                HIPCHK(hipMemsetAsync(b->d_tkflags, 0, b->cap[(const void *)&b->d_tkflags], up));
+            }
+        }
+    }
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint2) * (blk_cur + 1)));
@@ -852,6 +875,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.subcnt = b->d_subcnt;
     P.submk = b->d_submk;
     P.ckpt = b->d_ckpt;
+    P.tk_ckpt = b->d_tkck;
+    P.tk_flags = b->d_tkflags;
     P.dbg = nullptr;
     if (getenv("HJD_SYNC_PROF")) {
         need(slab_reserve(b, b->d_dbg, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1)));
@@ -1222,6 +1247,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     // a run of this batch whose sequential emulation may still be at work on the side stream owns the batch's slabs until it
     // is through (other batches are not held up)
     if (b->seq_pending) HIPCHK(hipStreamWaitEvent(s, b->seq_done, 0));
+    b->P.epoch = ++b->epoch; // what this run's sibling workgroups write into their flags (never 0)
+    if (b->epoch == 0xFFFFFFFFu) b->epoch = 0;
     if (names || b->ranges.size() <= 1) {
         hjd_batch::Range all{};
         all.i0 = 0;
