@@ -856,7 +856,7 @@ __device__ __forceinline__ void subseq_totals(uint32_t nph, uint32_t ww, CkY cky
 // NS_ = slots of the workgroup: HJD_SYNC_WG, or HJD_SYNC_WG_SMALL for the images whose whole scan fits one small workgroup
 // (k_sync_small: a thumbnail has a dozen subsequences; in a workgroup of 512 lanes it paid for 32 KB of tables, eight waves at
 // every barrier and a slot on a CU's two — 8192 images of 64 x 64, 3.8 M images/s, most of it this kernel).
-template <int MODE, uint32_t NS_>
+template <int MODE, uint32_t NS_, bool SIBS = false>
 __device__ __forceinline__ void sync_body(const HjdParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -873,7 +873,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     // Sibling workgroups (small batches only, HjdParams::tk_n): the grid holds tk_n + 1 workgroups per synchronisation workgroup,
     // the siblings first.  A sibling decodes round 0 over again with another block-in-MCU label from the second staging window on
     // and leaves its checkpoints in a slab of its own; see the refinement rounds.
-    const uint32_t TK = (MODE == 0 && !SMALL) ? P.tk_n : 0u;
+    static_assert(!SIBS || (MODE == 0 && !SMALL), "siblings: k_sync_sib only");
+    const uint32_t TK = SIBS ? P.tk_n : 0u; // (a kernel of its own, k_sync_sib: with the siblings' code merely present k_sync took 5 % longer)
     const uint32_t sib = TK ? TK - blockIdx.x / P.tk_nwg : 0u; // 0 = the workgroup proper
     const uint32_t bix = TK ? blockIdx.x % P.tk_nwg : blockIdx.x;
     const uint32_t bid = bix + (MODE == 0 ? (SMALL ? P.off_syncwg_small : P.off_syncwg) : P.off_repwg);
@@ -1297,8 +1298,9 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         // the dense rounds C per lane, side by side.
         const bool dense = n > T;
         uint32_t steps_done = 0;
-        auto walk = [&](auto nc_tag) {
+        auto walk = [&](auto nc_tag, auto sib_tag) {
             constexpr int NC = decltype(nc_tag)::value;
+            constexpr bool SIB = decltype(sib_tag)::value; // sibling trajectories to look at (a small batch); else their code is not there
             bool live[NC];
             uint32_t slot[NC], ph[NC], p[NC], z[NC], m[NC], cn[NC], co[NC], wmk[NC], wrow[NC], nblk[NC], nrec[NC];
             bool anylive = false;
@@ -1329,7 +1331,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 #pragma unroll
                     for (uint32_t t = 0; t < 3u; t++) { // the siblings' states at this window's end (owned subsequences, from the second window on)
                         sbl[c][t] = make_uint2(0xFFFFFFFFu, 0u);
-                        if (live[c] && ((tk_ok >> t) & 1u) && ph[c] != 0u && slot[c] >= nwarm) sbl[c][t] = *tkck(t, ph[c], slot[c]);
+                        if (SIB && live[c] && ((tk_ok >> t) & 1u) && ph[c] != 0u && slot[c] >= nwarm) sbl[c][t] = *tkck(t, ph[c], slot[c]);
                     }
                 }
                 decode_windows<NC>(E, live, wrow, ph, p, z, m, nblk, nrec, wmk);
@@ -1345,7 +1347,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     co[c] += ((old[c].y >> 9) & 2047u) | ((old[c].y >> 20) << 16);
                     *ck(ph[c], slot[c]) = make_uint2(p[c], st9 | (nblk[c] << 9) | (nrec[c] << 20));
                     int sibmet = -1; // in step with a sibling's decode instead?
-                    if (!met && tk_ok) {
+                    if (SIB && !met) {
 #pragma unroll
                         for (int t = 2; t >= 0; t--)
                             if (p[c] == sbl[c][t].x && st9 == (sbl[c][t].y & 511u)) sibmet = t;
@@ -1404,8 +1406,13 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                 }
             }
         };
-        if (dense) walk(std::integral_constant<int, (int)C>{});
-        else walk(std::integral_constant<int, 1>{});
+        if (SIBS && tk_ok) {
+            if (dense) walk(std::integral_constant<int, (int)C>{}, std::true_type{});
+            else walk(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            if (dense) walk(std::integral_constant<int, (int)C>{}, std::false_type{});
+            else walk(std::integral_constant<int, 1>{}, std::false_type{});
+        }
         stamp(0x10000 + steps_done); // wave 0's windows
         __syncthreads();
         stamp(0x20000);
@@ -1495,6 +1502,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 }
 
 __global__ __launch_bounds__(HJD_SYNC_THREADS) void k_sync(HjdParams P) { sync_body<0, HJD_SYNC_WG>(P); }
+__global__ __launch_bounds__(HJD_SYNC_THREADS) void k_sync_sib(HjdParams P) { sync_body<0, HJD_SYNC_WG, true>(P); } // small batches: with sibling trajectories
 __global__ __launch_bounds__(HJD_SYNC_WG_SMALL / HJD_SYNC_C) void k_sync_small(HjdParams P) { sync_body<0, HJD_SYNC_WG_SMALL>(P); }
 
 // the repair pass is its own kernel symbol so that profiles tell the two apart
@@ -1674,7 +1682,7 @@ static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
     // section: two host threads launching the same kernel for the first time with different sizes (decoders with different
     // subsequence sizes or staging windows) must not leave the attribute below what the table says was granted.
     static std::mutex mu;
-    static uint32_t granted[5][16];
+    static uint32_t granted[6][16];
     if (bytes <= 32768) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
@@ -1690,9 +1698,14 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (!nwg) return 0;
     if (mode == 0) {
         if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
-        HjdParams Q = P;
-        Q.tk_nwg = nwg; // the grid: tk_n sibling workgroups per synchronisation workgroup first, then the workgroups proper
-        hipLaunchKernelGGL(k_sync, dim3(nwg * (P.tk_n + 1u)), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, Q);
+        if (P.tk_n) {
+            if (set_dyn_lds(5, reinterpret_cast<const void *>(k_sync_sib), P.lds_bytes_sync)) return -1;
+            HjdParams Q = P;
+            Q.tk_nwg = nwg; // the grid: tk_n sibling workgroups per synchronisation workgroup first, then the workgroups proper
+            hipLaunchKernelGGL(k_sync_sib, dim3(nwg * (P.tk_n + 1u)), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, Q);
+        } else {
+            hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
+        }
     } else if (mode == 3) {
         if (set_dyn_lds(4, reinterpret_cast<const void *>(k_sync_small), P.lds_bytes_sync_small)) return -1;
         hipLaunchKernelGGL(k_sync_small, dim3(nwg), dim3(HJD_SYNC_WG_SMALL / HJD_SYNC_C), P.lds_bytes_sync_small, s, P);

@@ -7,6 +7,9 @@
 
 #define WAVE 64
 
+// (Raised wave priority — s_setprio 3 — for the entropy kernels, whose waves issue an instruction every 8-12 cycles at best and
+// queue for issue slots beside the back end's eight waves per SIMD: tried in round 4, the step got 1 % slower.)
+
 // image whose [first, first+count) range contains idx; `field` selects the first-index member
 template <typename F>
 __device__ __forceinline__ int find_image(const HjdImage *img, int n, uint32_t idx, F first_of)
