@@ -45,6 +45,8 @@
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
+#define HJD_WRITE_WG_SMALL 64   // lanes of the small final-pass workgroup (k_write_small: images with HjdImage::sync_small)
+#define HJD_ENT_CAP_SMALL 512u
 #define HJD_ENT_CAP 2048u      // block entries a final-pass workgroup collects in LDS before it writes them out together
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
@@ -116,6 +118,8 @@ struct HjdImage {
     uint32_t rec_cap;       // records reserved
     uint32_t conformant;    // hjd_options.conformant: DC reset at RSTn, true-cosine rounding IDCT, rounding colour
     uint32_t sync_small;    // 1: the image's one synchronisation workgroup is a small one (k_sync_small, its own numbering)
+    uint32_t write_small;   // 1: its final-pass workgroups are small ones (k_write_small, their own numbering)
+    uint32_t wgsum0;        // first entry of the image in wgsum[] (one array for both kinds of final-pass workgroups)
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)

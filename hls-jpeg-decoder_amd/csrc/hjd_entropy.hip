@@ -164,11 +164,12 @@ struct WriteCtx {
 // (Rounds 2-3 stored 16 bytes per block, with the mask of the slots the block's records fill, plus the DC difference once more
 // into a 2-byte array for the DC prediction kernels; every such lone store cost a 32-byte write: k_write wrote 1.8 times its
 // useful bytes.  The back end builds the masks from the records themselves — it touches every record anyway.)
+template <uint32_t ENTCAP>
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
     if (W.bfirst != 0xFFFFFFFFu) {
         const uint32_t idx = b - W.b0, rel = W.bfirst - W.r0;
-        if (idx < HJD_ENT_CAP && rel < 0xFFFFu) W.ent[idx] = rel | (W.bdc << 16);
+        if (idx < ENTCAP && rel < 0xFFFFu) W.ent[idx] = rel | (W.bdc << 16);
         else W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu); // more blocks or records than the staging holds: straight out
     }
     W.bfirst = 0xFFFFFFFFu;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *_
 // record.  Everything a DC symbol does is predicated (selects) instead of branched: some lane of a wave is at a DC symbol, at
 // an end of block and at an AC coefficient in nearly every iteration, so every branch region is executed by every wave anyway
 // (round 2's loop: ~90 vector instructions per iteration, a third of them moves and mask juggling around the regions).
-template <bool RESTART>
+template <bool RESTART, uint32_t WGSZ, uint32_t ENTCAP>
 __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t stride, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
@@ -358,14 +359,14 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 w = HJD_REC_PAD;
             }
             static_assert(HJD_REC_RUN % 4 == 0 && (HJD_REC_RUN & (HJD_REC_RUN - 1)) == 0, "16-byte pieces");
-            W.ring[(nrec & (HJD_REC_RUN - 1u)) * HJD_WRITE_WG] = w;
+            W.ring[(nrec & (HJD_REC_RUN - 1u)) * WGSZ] = w;
             if ((nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u) { // a burst is complete: whole, aligned sectors
                 if (nrec < W.rec_cap) {
                     uint32_t *dst = W.rec + (nrec - (HJD_REC_RUN - 1u));
 #pragma unroll
                     for (uint32_t q = 0; q < HJD_REC_RUN / 4u; q++)
-                        store_records(dst + 4u * q, W.ring[(4u * q) * HJD_WRITE_WG], W.ring[(4u * q + 1u) * HJD_WRITE_WG],
-                                      W.ring[(4u * q + 2u) * HJD_WRITE_WG], W.ring[(4u * q + 3u) * HJD_WRITE_WG]);
+                        store_records(dst + 4u * q, W.ring[(4u * q) * WGSZ], W.ring[(4u * q + 1u) * WGSZ],
+                                      W.ring[(4u * q + 2u) * WGSZ], W.ring[(4u * q + 3u) * WGSZ]);
                 } else {
                     flags |= HJD_FLAG_OVERRUN;
                 }
@@ -380,7 +381,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         rd.advance(tot);
         if (blk_end) { // EOB or last coefficient: next block (DecodeMCU order, loadjpg.cpp:945-997)
             z = 0u;
-            write_block_entry(W, nblk);
+            write_block_entry<ENTCAP>(W, nblk);
             nblk++;
             if (nblk == W.nblocks) {
                 W.blk[nblk] = make_uint2(nrec, 0u); // end of the last block's records
@@ -441,13 +442,13 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
     }
 }
 
-template <bool RESTART>
+template <bool RESTART, uint32_t WGSZ, uint32_t ENTCAP>
 __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t stride, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
 {
     if (!RESTART) {
-        write_core<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
         return;
     }
     // see sync_span.  The plain loop keeps no count of the blocks left in the interval: it is brought up to date after it, and an
@@ -458,7 +459,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
         const uint32_t mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
         if (p + 40u <= mnext) {
             const uint32_t before = nblk;
-            write_core<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
+            write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
             const uint32_t done = nblk - before;
             if (!rc.conf && rc.ri_blocks != 0u) {
                 if (done >= rc.left && before + rc.left < W.nblocks) {
@@ -470,7 +471,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
             }
             if (p >= end || nblk >= W.nblocks) break;
         }
-        write_core<true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        write_core<true, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
     }
 }
 
@@ -1434,7 +1435,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         // subsequences, which a synchronisation workgroup's range [own0, own1) cuts anywhere: LDS atomics per group, then one
         // global atomic per group and counter.  A stale workgroup border is still caught: k_write
         // checks the induction step for every subsequence and the host re-synchronises.
-        const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows); // subsequences per final-pass workgroup (powers of two)
+        const uint32_t G = (im.write_small ? HJD_WRITE_WG_SMALL : HJD_WRITE_WG) / (nph / P.write_windows); // subsequences per final-pass workgroup (powers of two)
         const uint32_t wq0 = own0 / G;
         __syncthreads(); // everyone is done with the work list
 #pragma unroll
@@ -1456,15 +1457,15 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         for (uint32_t t = tid; t < NS; t += T) {
             const uint32_t wq = wq0 + t;
             if (t <= (own1 - 1u) / G - wq0 && wq < im.nwritewg && (s_lp[t] | s_lst[t])) {
-                atomicAdd(&P.wgsum[im.writewg0 + wq].x, s_lp[t]);
-                atomicAdd(&P.wgsum[im.writewg0 + wq].y, s_lst[t]);
+                atomicAdd(&P.wgsum[im.wgsum0 + wq].x, s_lp[t]);
+                atomicAdd(&P.wgsum[im.wgsum0 + wq].y, s_lst[t]);
             }
         }
         if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
     }
     if (MODE == 2) {
         // The same totals after a repair (host re-synchronisation): written, not added — a repair workgroup holds whole groups.
-        const uint32_t G = HJD_WRITE_WG / (nph / P.write_windows);
+        const uint32_t G = (im.write_small ? HJD_WRITE_WG_SMALL : HJD_WRITE_WG) / (nph / P.write_windows);
         __syncthreads(); // everyone is done with the work list
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) {
@@ -1482,7 +1483,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                 tr += s_lst[t * G + q];
             }
             const uint32_t wq = wg * (NS / G) + t;
-            if (wq < im.nwritewg) P.wgsum[im.writewg0 + wq] = make_uint2(tb, tr);
+            if (wq < im.nwritewg) P.wgsum[im.wgsum0 + wq] = make_uint2(tb, tr);
         }
         if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
     }
@@ -1516,13 +1517,17 @@ __global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair_totals(HjdParams P)
 // (Round 2 ran one lane per 2048-bit subsequence: 1.1 resident waves per SIMD, every lane a chain of ~430 symbol steps.)
 // A workgroup covers G = HJD_WRITE_WG / (spans per subsequence) whole subsequences:
 // their words are loaded once, coalesced, into LDS ([word][row], rows + 1 apart), and every lane decodes its span from there.
-__global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
+// WGSZ lanes: WGSZ, or WGSZ_SMALL (one wave) for the images with a small synchronisation workgroup (k_write_small:
+// a thumbnail is a few dozen staging windows; ENTCAP = block entries collected in LDS).
+template <uint32_t WGSZ, uint32_t ENTCAP>
+__device__ __forceinline__ void write_body(const HjdParams &P)
 {
+    constexpr bool SMALL = WGSZ != HJD_WRITE_WG;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t bid = blockIdx.x + P.off_writewg;
-    const int ii = (int)P.map_writewg[bid];
+    const uint32_t bid = blockIdx.x + (SMALL ? P.off_writewg_small : P.off_writewg);
+    const int ii = (int)(SMALL ? P.map_writewg_small[bid] : P.map_writewg[bid]);
     const HjdImage &im = P.img[ii];
     const uint32_t wg = bid - im.writewg0;
 
@@ -1531,27 +1536,27 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t *s_w = s_dyn + P.lds_state_word;
     uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_w + 48);
-    uint32_t *s_ring = s_w + 64;                        // [HJD_REC_RUN][HJD_WRITE_WG]: the lanes' bursts in the making
-    uint32_t *s_ent = s_ring + HJD_REC_RUN * HJD_WRITE_WG; // [HJD_ENT_CAP]: block entries in the making
-    uint32_t *s_rows = s_ent + HJD_ENT_CAP;
+    uint32_t *s_ring = s_w + 64;                        // [HJD_REC_RUN][WGSZ]: the lanes' bursts in the making
+    uint32_t *s_ent = s_ring + HJD_REC_RUN * WGSZ; // [ENTCAP]: block entries in the making
+    uint32_t *s_rows = s_ent + ENTCAP;
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     const uint32_t S = P.subseq_bits, wps = S >> 5, nph = wps / P.phase_words;
     const uint32_t WWN = P.write_windows, nu = nph / WWN; // windows per lane, lanes per subsequence
     const uint32_t lnu = (uint32_t)__ffs((int)nu) - 1u;    // nu is a power of two
-    const uint32_t G = HJD_WRITE_WG >> lnu, stride = G + 1u; // subsequences of this workgroup; words between a row's words in LDS
+    const uint32_t G = WGSZ >> lnu, stride = G + 1u; // subsequences of this workgroup; words between a row's words in LDS
     const uint32_t total_bits = P.st[ii].ustream_len * 8u;
     const uint32_t nsub = (total_bits + S - 1) / S;
-    if (wg * HJD_WRITE_WG >= nsub * nu) return; // capacity-based grid: nothing in this workgroup
+    if (wg * WGSZ >= nsub * nu) return; // capacity-based grid: nothing in this workgroup
     load_tables<false>(ts, s_lut, s_sec);
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
-    for (uint32_t k = tid; k < HJD_ENT_CAP; k += HJD_WRITE_WG) s_ent[k] = 0xFFFFFFFFu;
+    for (uint32_t k = tid; k < ENTCAP; k += WGSZ) s_ent[k] = 0xFFFFFFFFu;
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
     {   // the workgroup's rows: word k of row i0 + r -> s_rows[k * stride + r] (rows past the scan's end stay unread)
         const uint32_t i0 = wg * G, nrows = min(G, nsub - i0), lw = P.log2_words;
         const uint32_t *wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
         const uint32_t lg = (uint32_t)__ffs((int)G) - 1u; // G is a power of two
-        for (uint32_t idx = tid; idx < G * (wps + 2u); idx += HJD_WRITE_WG) {
+        for (uint32_t idx = tid; idx < G * (wps + 2u); idx += WGSZ) {
             const uint32_t k = idx >> lg, r = idx & (G - 1u);
             if (r < nrows) s_rows[k * stride + r] = row_base(wbase, i0 + r, lw)[(size_t)k * 64u]; // (non-temporal loads here: no difference)
         }
@@ -1559,7 +1564,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
 
     // lane tid <-> span u: subsequence u / nu, windows [(u % nu) * WWN, + WWN)
     const uint2 *ckc = P.ckpt + (size_t)im.sub0 * nph; // [window][subsequence] of this image
-    const uint32_t u = wg * HJD_WRITE_WG + tid;
+    const uint32_t u = wg * WGSZ + tid;
     const uint32_t i = u >> lnu, ph = (u & (nu - 1u)) * WWN;
     const bool valid = i < nsub;
     const uint32_t g = im.sub0 + i;
@@ -1573,8 +1578,8 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         }
     // where the spans' blocks and records go: totals of the workgroups before this one + scan inside
     uint32_t pb = 0, pr = 0;
-    for (uint32_t k = tid; k < wg; k += HJD_WRITE_WG) {
-        const uint2 t = P.wgsum[im.writewg0 + k];
+    for (uint32_t k = tid; k < wg; k += WGSZ) {
+        const uint2 t = P.wgsum[im.wgsum0 + k];
         pb += t.x;
         pr += t.y;
     }
@@ -1584,7 +1589,7 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     uint32_t blk = base_b + block_excl_scan(my_blocks, s_w, &tot_b);
     uint32_t nrec = base_r + block_excl_scan((my_recs + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
     uint32_t flags = 0;
-    if (tid == 0 && (wg + 1u) * HJD_WRITE_WG >= nsub * nu) { // the workgroup that holds the last span
+    if (tid == 0 && (wg + 1u) * WGSZ >= nsub * nu) { // the workgroup that holds the last span
         P.st[ii].total_blocks = base_b + tot_b;
         if (base_b + tot_b < im.nblocks) flags |= HJD_FLAG_SHORT;
     }
@@ -1632,9 +1637,9 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
         if (im.restart) {
             rc.nmark = min(P.st[ii].nmarkers, im.mark_cap);
             rc.mk = min(P.submk[g], rc.nmark); // first marker past the subsequence's first bit (k_sync); write_span moves it past p
-            write_span<true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
+            write_span<true, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
         } else {
-            write_span<false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
+            write_span<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
         }
     }
     // the span must end in the state, and with the record count, its checkpoints hold (else the places of everything
@@ -1642,16 +1647,16 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     if (go && blk < im.nblocks && !(flags & (HJD_FLAG_BAD_CODE | HJD_FLAG_OVERRUN)) &&
         (p != mine.x || (z | (m << 6)) != (mine.y & 511u) || nrec - nrec0 != my_recs))
         flags |= HJD_FLAG_NOT_CONVERGED;
-    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry(W, blk); // the span ends inside a block it owns
+    if (go && blk < im.nblocks && W.bfirst != 0xFFFFFFFFu) write_block_entry<ENTCAP>(W, blk); // the span ends inside a block it owns
     if (go && (nrec & (HJD_REC_RUN - 1u))) { // last, partial burst: records first, padding after
         const uint32_t k = nrec & (HJD_REC_RUN - 1u);
-        for (uint32_t q = k; q < HJD_REC_RUN; q++) W.ring[q * HJD_WRITE_WG] = HJD_REC_PAD;
+        for (uint32_t q = k; q < HJD_REC_RUN; q++) W.ring[q * WGSZ] = HJD_REC_PAD;
         if (nrec + HJD_REC_RUN - k <= im.rec_cap) {
             uint32_t *dst = W.rec + (nrec - k);
 #pragma unroll
             for (uint32_t q = 0; q < HJD_REC_RUN / 4u; q++)
-                store_records(dst + 4u * q, W.ring[(4u * q) * HJD_WRITE_WG], W.ring[(4u * q + 1u) * HJD_WRITE_WG], W.ring[(4u * q + 2u) * HJD_WRITE_WG],
-                              W.ring[(4u * q + 3u) * HJD_WRITE_WG]);
+                store_records(dst + 4u * q, W.ring[(4u * q) * WGSZ], W.ring[(4u * q + 1u) * WGSZ], W.ring[(4u * q + 2u) * WGSZ],
+                              W.ring[(4u * q + 3u) * WGSZ]);
         } else {
             flags |= HJD_FLAG_OVERRUN;
         }
@@ -1664,13 +1669,16 @@ __global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P)
     __syncthreads();
     {
         uint2 *blk_out = P.blk + im.blk_off + base_b;
-        const uint32_t n = min(tot_b + 1u, HJD_ENT_CAP);
-        for (uint32_t k = tid; k < n; k += HJD_WRITE_WG) {
+        const uint32_t n = min(tot_b + 1u, ENTCAP);
+        for (uint32_t k = tid; k < n; k += WGSZ) {
             const uint32_t v = s_ent[k];
             if (v != 0xFFFFFFFFu) blk_out[k] = make_uint2(base_r + (v & 0xFFFFu), v >> 16);
         }
     }
 }
+
+__global__ __launch_bounds__(HJD_WRITE_WG) void k_write(HjdParams P) { write_body<HJD_WRITE_WG, HJD_ENT_CAP>(P); }
+__global__ __launch_bounds__(HJD_WRITE_WG_SMALL) void k_write_small(HjdParams P) { write_body<HJD_WRITE_WG_SMALL, HJD_ENT_CAP_SMALL>(P); }
 
 // ---- launch wrappers --------------------------------------------------------------------------
 
@@ -1682,7 +1690,7 @@ static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
     // section: two host threads launching the same kernel for the first time with different sizes (decoders with different
     // subsequence sizes or staging windows) must not leave the attribute below what the table says was granted.
     static std::mutex mu;
-    static uint32_t granted[6][16];
+    static uint32_t granted[7][16];
     if (bytes <= 32768) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
@@ -1720,9 +1728,15 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     return e_ == hipSuccess ? 0 : (int)e_;
 }
 
-int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s)
+int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s, int small)
 {
     if (!nwg) return 0;
+    if (small) {
+        if (set_dyn_lds(6, reinterpret_cast<const void *>(k_write_small), P.lds_bytes_write_small)) return -1;
+        hipLaunchKernelGGL(k_write_small, dim3(nwg), dim3(HJD_WRITE_WG_SMALL), P.lds_bytes_write_small, s, P);
+        hipError_t e2_ = hipGetLastError();
+        return e2_ == hipSuccess ? 0 : (int)e2_;
+    }
     if (set_dyn_lds(3, reinterpret_cast<const void *>(k_write), P.lds_bytes_write)) return -1;
     hipLaunchKernelGGL(k_write, dim3(nwg), dim3(HJD_WRITE_WG), P.lds_bytes_write, s, P);
     hipError_t e_ = hipGetLastError();

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(HjdParams P)
         }
     }
     if (c == im.chunk0) // ... and the final-pass workgroups' totals, which k_sync adds up
-        for (uint32_t k = threadIdx.x; k < im.nwritewg; k += UNSTUFF_T) P.wgsum[im.writewg0 + k] = make_uint2(0u, 0u);
+        for (uint32_t k = threadIdx.x; k < im.nwritewg; k += UNSTUFF_T) P.wgsum[im.wgsum0 + k] = make_uint2(0u, 0u);
 }
 
 __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)

@@ -172,7 +172,7 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
+    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
@@ -193,7 +193,7 @@ struct hjd_batch {
     hipStream_t seq_stream = nullptr;
     hipEvent_t seq_fork = nullptr, seq_done = nullptr;
     bool seq_pending = false;
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, ngroups = 0, ndcchunks = 0;
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, nwritewg_small = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
     uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
@@ -527,7 +527,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->out_bytes.clear();
     b->hdr_bytes.clear();
     b->ranges.clear();
-    b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->ngroups = b->ndcchunks = b->nmarks = 0;
+    b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->nwritewg_small = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
     b->dirty_decodes = 0;
@@ -624,9 +624,19 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.repwg0 = b->nrepwg;
         im.nrepwg = (im.nsub_cap + HJD_SYNC_WG - 1) / HJD_SYNC_WG;
         b->nrepwg += im.nrepwg;
-        im.writewg0 = b->nwritewg;
-        im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nu + HJD_WRITE_WG - 1) / HJD_WRITE_WG); // one lane per span of wwn windows
-        b->nwritewg += im.nwritewg;
+        // one lane per span of wwn windows; the images with a small synchronisation workgroup get small final-pass workgroups too
+        // (up to two of them: a 256 x 256 image in five small workgroups — five loads of the tables — took 0.55 ms per 4096 images
+        // against 0.37 in two large ones)
+        im.write_small = (im.sync_small && nu <= HJD_WRITE_WG_SMALL && (uint64_t)im.nsub_cap * nu <= 2u * HJD_WRITE_WG_SMALL) ? 1u : 0u;
+        if (im.write_small) {
+            im.writewg0 = b->nwritewg_small;
+            im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nu + HJD_WRITE_WG_SMALL - 1) / HJD_WRITE_WG_SMALL);
+            b->nwritewg_small += im.nwritewg;
+        } else {
+            im.writewg0 = b->nwritewg;
+            im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nu + HJD_WRITE_WG - 1) / HJD_WRITE_WG);
+            b->nwritewg += im.nwritewg;
+        }
         im.dcchunk0 = b->ndcchunks;
         im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
         b->ndcchunks += im.ndcchunk;
@@ -688,6 +698,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->alg_bytes += (uint64_t)im.scan_len + j.header_bytes + (uint64_t)im.width * im.height * 3;
     }
     b->nimg = (int)b->img.size();
+    for (auto &im : b->img) im.wgsum0 = im.write_small ? b->nwritewg + im.writewg0 : im.writewg0; // wgsum[]: the large workgroups' totals, then the small ones'
     b->rst_images.clear();
     for (int k = 0; k < b->nimg; k++)
         if (b->img[k].restart) b->rst_images.push_back((uint32_t)k);
@@ -723,6 +734,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_bytes_sync_small = (P.lds_state_word_s + 5 * HJD_SYNC_WG_SMALL + HJD_SYNC_WG_SMALL / 4 + 96 + (HJD_SYNC_WG_SMALL / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
         P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + HJD_ENT_CAP + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
+        P.lds_bytes_write_small = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG_SMALL + HJD_ENT_CAP_SMALL +
+                                   (S / 32 + 2) * (HJD_WRITE_WG_SMALL / (nu <= HJD_WRITE_WG_SMALL ? nu : HJD_WRITE_WG_SMALL) + 1)) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
 
@@ -761,7 +774,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             }
         }
     }
-    need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * b->nwritewg));
+    need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint2) * (blk_cur + 1)));
     need(slab_reserve(b, b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
@@ -794,7 +807,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         const size_t off_sync_small = fill_sync(1u);
         if (off_sync_small == (size_t)-1) return HJD_ERR_INTERNAL;
         off_rep = fill(&HjdImage::repwg0, &HjdImage::nrepwg);
-        off_write = fill(&HjdImage::writewg0, &HjdImage::nwritewg);
+        auto fill_write = [&](uint32_t small) {
+            const size_t at = maps.size();
+            for (int k = 0; k < b->nimg; k++) {
+                if (b->img[k].write_small != small) continue;
+                if (maps.size() != at + b->img[k].writewg0) return (size_t)-1;
+                maps.insert(maps.end(), b->img[k].nwritewg, (uint32_t)k);
+            }
+            return at;
+        };
+        off_write = fill_write(0u);
+        const size_t off_write_small = fill_write(1u);
+        if (off_write_small == (size_t)-1) return HJD_ERR_INTERNAL;
         off_dc = fill(&HjdImage::dcchunk0, &HjdImage::ndcchunk);
         if (off_chunk == (size_t)-1 || off_sync == (size_t)-1 || off_rep == (size_t)-1 || off_write == (size_t)-1 || off_dc == (size_t)-1)
             return HJD_ERR_INTERNAL;
@@ -822,6 +846,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->P.map_syncwg_small = b->d_maps + off_sync_small;
         b->P.map_repwg = b->d_maps + off_rep;
         b->P.map_writewg = b->d_maps + off_write;
+        b->P.map_writewg_small = b->d_maps + off_write_small;
         b->P.map_dcchunk = b->d_maps + off_dc;
         b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
         b->P.rst_list = b->d_maps + off_rst;
@@ -892,7 +917,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
-    P.off_chunk = P.off_syncwg = P.off_syncwg_small = P.off_repwg = P.off_writewg = P.off_img = P.off_dcchunk = P.off_group = 0;
+    P.off_chunk = P.off_syncwg = P.off_syncwg_small = P.off_repwg = P.off_writewg = P.off_writewg_small = P.off_img = P.off_dcchunk = P.off_group = 0;
     {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
         uint64_t total_px = 0;
         for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
@@ -932,7 +957,21 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 }
             }
             r.repwg0 = a.repwg0;       r.nrepwg = z.repwg0 + z.nrepwg - a.repwg0;
-            r.writewg0 = a.writewg0;   r.nwritewg = z.writewg0 + z.nwritewg - a.writewg0;
+            {   // final-pass workgroups of the range, per numbering
+                bool have_big = false, have_small = false;
+                for (int q = i0; q < i1; q++) {
+                    const HjdImage &im = b->img[q];
+                    if (im.write_small) {
+                        if (!have_small) r.swritewg0 = im.writewg0;
+                        have_small = true;
+                        r.nswritewg = im.writewg0 + im.nwritewg - r.swritewg0;
+                    } else {
+                        if (!have_big) r.writewg0 = im.writewg0;
+                        have_big = true;
+                        r.nwritewg = im.writewg0 + im.nwritewg - r.writewg0;
+                    }
+                }
+            }
             r.dc0 = a.dcchunk0;        r.ndc = z.dcchunk0 + z.ndcchunk - a.dcchunk0;
             r.group0 = a.group0;       r.ngroup = z.group0 + z.ngroups - a.group0;
             r.blk0 = (size_t)a.blk_off;
@@ -1064,7 +1103,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->rec_entries = b.nrec + HJD_REC_RUN;
     o->out_bytes = b.out_total;
     o->substate_entries = b.nsub;
-    o->wgsum_entries = b.nwritewg;
+    o->wgsum_entries = (size_t)b.nwritewg + b.nwritewg_small;
     o->dcsum_entries = 3 * ((size_t)b.ndcchunks + 1);
     {   // what batch_build allocates
         const size_t nph = (b.P.subseq_bits / 32) / b.P.phase_words;
@@ -1135,6 +1174,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     P.off_syncwg_small = r.ssyncwg0;
     P.off_repwg = r.repwg0;
     P.off_writewg = r.writewg0;
+    P.off_writewg_small = r.swritewg0;
     P.off_img = (uint32_t)r.i0;
     P.off_dcchunk = r.dc0;
     P.off_group = r.group0;
@@ -1150,6 +1190,8 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         return HJD_OK;
     };
     int rc;
+    bool small_write_on_side = false;
+    hipEvent_t side_done = nullptr;
     const int nrep = b->dec->sync_launches - 1; // repair launches; the last one also leaves k_write's totals
     if (!from_resync) {
         if ((rc = mark("unstuff"))) return rc; // k_unstuff_count also clears the per-image state
@@ -1175,17 +1217,20 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         if ((rc = mark("huff_sync"))) return rc;
         // the images with a small workgroup of their own: beside the large ones when the range holds both kinds
         hjd_batch::SideStream *ss = (r.nssyncwg && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
+        small_write_on_side = ss && nrep == 0; // the small images' final pass follows their synchronisation on the side stream
         if (ss) {
             if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->st, ss->fork, 0) != hipSuccess) return HJD_ERR_INTERNAL;
             if (hjd_launch_sync(P, r.nssyncwg, 3, ss->st)) return HJD_ERR_INTERNAL;
+            if (small_write_on_side && hjd_launch_write(P, r.nswritewg, ss->st, 1)) return HJD_ERR_INTERNAL;
             if (hipEventRecord(ss->done, ss->st) != hipSuccess) return HJD_ERR_INTERNAL;
         }
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
-        if (ss) {
+        if (ss && !small_write_on_side) {
             if (hipStreamWaitEvent(s, ss->done, 0) != hipSuccess) return HJD_ERR_INTERNAL;
-        } else if (hjd_launch_sync(P, r.nssyncwg, 3, s)) {
+        } else if (!ss && hjd_launch_sync(P, r.nssyncwg, 3, s)) {
             return HJD_ERR_INTERNAL;
         }
+        side_done = ss ? ss->done : nullptr;
         if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (record_stagger && stagger_after == 1 && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (nrep > 0 && (rc = mark("huff_repair"))) return rc;
@@ -1197,6 +1242,11 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     }
     if ((rc = mark("huff_write"))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
+    if (small_write_on_side) {
+        if (hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return HJD_ERR_INTERNAL; // the side stream joins here
+    } else if (hjd_launch_write(P, r.nswritewg, s, 1)) {
+        return HJD_ERR_INTERNAL;
+    }
     if (record_stagger && stagger_after == 2 && !from_resync && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
     if ((rc = mark("dc_scan"))) return rc;
     if (hjd_launch_dcscan(P, r.ndc, s)) return HJD_ERR_INTERNAL;
@@ -1258,6 +1308,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.nssyncwg = b->nsyncwg_small;
         all.nrepwg = b->nrepwg;
         all.nwritewg = b->nwritewg;
+        all.nswritewg = b->nwritewg_small;
         all.ndc = b->ndcchunks;
         all.ngroup = b->ngroups;
         all.nblk = b->nblk_entries;
