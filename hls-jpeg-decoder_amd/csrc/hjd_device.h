@@ -45,6 +45,7 @@
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
+#define HJD_SEQ_MAX_BITS 65536u // scans up to this many bits go to k_sync_seq (one lane per image)
 #define HJD_WRITE_WG_SMALL 64   // lanes of the small final-pass workgroup (k_write_small: images with HjdImage::sync_small)
 #define HJD_ENT_CAP_SMALL 512u
 #define HJD_ENT_CAP 2048u      // block entries a final-pass workgroup collects in LDS before it writes them out together
@@ -117,7 +118,8 @@ struct HjdImage {
     uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
     uint32_t rec_cap;       // records reserved
     uint32_t conformant;    // hjd_options.conformant: DC reset at RSTn, true-cosine rounding IDCT, rounding colour
-    uint32_t sync_small;    // 1: the image's one synchronisation workgroup is a small one (k_sync_small, its own numbering)
+    uint32_t sync_small;    // 1: the image's one synchronisation workgroup is a small one (k_sync_small, its own numbering);
+                            // 2: none at all — a lane of k_sync_seq decodes the whole scan (thumbnails)
     uint32_t write_small;   // 1: its final-pass workgroups are small ones (k_write_small, their own numbering)
     uint32_t wgsum0;        // first entry of the image in wgsum[] (one array for both kinds of final-pass workgroups)
     uint64_t raw_off;       // byte offset into raw slab

@@ -1510,6 +1510,95 @@ __global__ __launch_bounds__(HJD_SYNC_WG_SMALL / HJD_SYNC_C) void k_sync_small(H
 __global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair(HjdParams P) { sync_body<1, HJD_SYNC_WG>(P); }
 __global__ __launch_bounds__(HJD_SYNC_THREADS) void k_repair_totals(HjdParams P) { sync_body<2, HJD_SYNC_WG>(P); }
 
+// k_sync_seq — thumbnails.  A scan of a few kilobytes is a dozen subsequences: with a synchronisation workgroup of its own (even the
+// one-wave kind) an image paid for 32 KB of tables, the rounds' barriers and a place on a CU for a few lanes' work — 8192 images of
+// 64 x 64: 0.6 ms.  Here ONE LANE decodes ONE image from its first bit to its last, in the synchronisation form, no guessing and
+// no rounds; the 64 images of a workgroup share their tables (the host groups images by table set and sampling) and the loop of
+// sync_window does not care that its lanes work on different images.  Leaves what k_sync leaves: checkpoints, subsequence
+// records, the final-pass workgroups' totals.  The time is that of the longest image of a wave (12 kbit: 0.2 ms).
+__global__ __launch_bounds__(64) void k_sync_seq(HjdParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bid = blockIdx.x + P.off_seqwg;
+    const uint32_t *list = P.seq_list + (size_t)bid * 64u;
+    const uint32_t i0 = list[0]; // never empty: the group's first image gives the tables and the sampling
+    const uint32_t iid = list[tid];
+    const bool have = iid != 0xFFFFFFFFu;
+    const HjdImage &im0 = P.img[i0];
+    const HjdImage &im = P.img[have ? iid : i0];
+    const HjdTableSet *ts = &P.tabs[im0.tabset];
+
+    uint32_t *s_lut = s_dyn;
+    uint32_t *s_sec = s_dyn + P.lds_sec_word_s;
+    uint32_t *s_w = s_dyn + P.lds_state_word_s;
+    uint2 *s_mt = reinterpret_cast<uint2 *>(s_w);        // 8 entries (unused here: restart streams are not sent this way)
+    uint4 *s_mt4 = reinterpret_cast<uint4 *>(s_w + 16);  // 8 entries
+    uint32_t *s_rows = s_w + 48;                         // one staging window per lane
+
+    RowEnv E;
+    E.P = &P;
+    E.im = &im;
+    E.L = {reinterpret_cast<const uint16_t *>(s_lut), reinterpret_cast<const uint16_t *>(s_sec), s_mt};
+    E.tabY = table_pair(ts->slot_pack, 0, 4u);
+    E.tabCb = table_pair(ts->slot_pack, 1, 4u);
+    E.tabCr = table_pair(ts->slot_pack, 2, 4u);
+    E.mt4_addr = lds_addr(s_mt4);
+    E.sec_addr = lds_addr(s_sec);
+    fill_block_table(s_mt4, E.mt4_addr, im0.nb, im0.nby, lds_addr(s_lut), E.tabY, E.tabCb, E.tabCr, tid);
+    E.wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
+    E.s_stage = s_rows;
+    E.total_bits = have ? P.st[iid].ustream_len * 8u : 0u;
+    E.nmark = 0u;
+    load_tables<true>(ts, s_lut, s_sec);
+    __syncthreads();
+
+    const uint32_t S = P.subseq_bits, nph = (S >> 5) / P.phase_words;
+    const uint32_t nsub = (E.total_bits + S - 1u) / S;
+    const uint32_t G = (im.write_small ? HJD_WRITE_WG_SMALL : HJD_WRITE_WG) / (nph / P.write_windows); // subsequences per final-pass workgroup
+    uint2 *const ckc = P.ckpt + (size_t)im.sub0 * nph; // + window * nsub_cap + subsequence
+    uint32_t p[1] = {0u}, z[1] = {0u}, m[1] = {0u}, nblk[1], nrec[1], mk[1] = {0u}, row[1] = {0u}, ph[1] = {0u};
+    uint32_t up = 0u, uzm = 0u;      // the state the current subsequence starts from
+    uint32_t sb = 0u, sr = 0u, rr = 0u, tb = 0u, tr = 0u; // blocks / padded records of the current final-pass group, records of the current
+                                     // k_write lane (write_windows windows), blocks / records of the subsequence
+    bool live[1] = {have && nsub != 0u};
+    while (__any(live[0])) {
+        decode_windows<1>(E, live, row, ph, p, z, m, nblk, nrec, mk);
+        if (live[0]) {
+            ckc[(size_t)ph[0] * im.nsub_cap + row[0]] = make_uint2(p[0], z[0] | (m[0] << 6) | (nblk[0] << 9) | (nrec[0] << 20));
+            tb += nblk[0];
+            tr += nrec[0];
+            sb += nblk[0];
+            rr += nrec[0];
+            if (((ph[0] + 1u) & (P.write_windows - 1u)) == 0u) { // a k_write lane's span ends: its run of records is padded to whole bursts
+                sr += (rr + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
+                rr = 0u;
+            }
+            if (++ph[0] == nph) { // the subsequence is complete
+                const uint32_t g = im.sub0 + row[0], ezm = z[0] | (m[0] << 8);
+                P.substate[g] = make_uint4(p[0], ezm, up, uzm);
+                P.subcnt[g] = tb | (tr << 16);
+                up = p[0];
+                uzm = ezm;
+                tb = tr = 0u;
+                ph[0] = 0u;
+                row[0]++;
+                if ((row[0] & (G - 1u)) == 0u || row[0] == nsub) { // a final-pass workgroup's subsequences are complete
+                    const uint32_t wq = (row[0] - 1u) / G;
+                    if (wq < im.nwritewg) P.wgsum[im.wgsum0 + wq] = make_uint2(sb, sr); // (zeroed by k_unstuff_count; nobody else adds here)
+                    sb = sr = 0u;
+                }
+                live[0] = row[0] < nsub;
+            }
+        }
+    }
+    if (have) {
+        HjdImageState &st = P.st[iid];
+        st.sync_decodes = nsub;
+        if (nsub == 0u) atomicOr(&st.flags, HJD_FLAG_SHORT); // a scan without a single data byte
+    }
+}
+
 // ---- stage 3: final entropy decode, coefficients out ------------------------------------------
 
 // One lane per span of P.write_windows staging windows of a subsequence: k_sync's checkpoints hold the decoder state at every
@@ -1690,7 +1779,7 @@ static int set_dyn_lds(int which, const void *fn, uint32_t bytes)
     // section: two host threads launching the same kernel for the first time with different sizes (decoders with different
     // subsequence sizes or staging windows) must not leave the attribute below what the table says was granted.
     static std::mutex mu;
-    static uint32_t granted[7][16];
+    static uint32_t granted[8][16];
     if (bytes <= 32768) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return -1;
@@ -1724,6 +1813,15 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
         if (set_dyn_lds(2, reinterpret_cast<const void *>(k_repair_totals), P.lds_bytes_sync)) return -1;
         hipLaunchKernelGGL(k_repair_totals, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
     }
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+int hjd_launch_sync_seq(const HjdParams &P, uint32_t nwg, hipStream_t s)
+{
+    if (!nwg) return 0;
+    if (set_dyn_lds(7, reinterpret_cast<const void *>(k_sync_seq), P.lds_bytes_sync_seq)) return -1;
+    hipLaunchKernelGGL(k_sync_seq, dim3(nwg), dim3(64), P.lds_bytes_sync_seq, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

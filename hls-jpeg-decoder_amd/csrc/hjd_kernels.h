@@ -46,6 +46,9 @@ struct HjdParams {
     uint32_t off_chunk, off_syncwg, off_syncwg_small, off_repwg, off_writewg, off_writewg_small, off_img, off_dcchunk, off_group;
     uint32_t conformant;       // hjd_options.conformant: selects the conformant instantiation of the back end
     uint32_t gate_emulated;    // k_idct_color: 1 = only images the sequential emulation has just decoded (HjdImageState::emulated)
+    const uint32_t *seq_list;  // k_sync_seq: per workgroup 64 device images (all ones = none) that share table set and sampling
+    uint32_t off_seqwg;
+    uint32_t lds_bytes_sync_seq;
     const uint32_t *rst_list;  // device images that carry DRI, ascending (the sequential emulation's candidates)
     const uint32_t *rst_groups; // the back-end workgroups (batch-global numbers) of those images: the grid of the gated launch
     uint32_t subseq_bits;      // power of two, 64..4096
@@ -68,6 +71,7 @@ int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s); // mode 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_sync_small
 int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s, int small = 0);
+int hjd_launch_sync_seq(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);
 int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s); // candidates rst_list[first .. first + n): those flagged DIRTY are decoded
 int hjd_launch_color_table(uint8_t *d_out, hipStream_t s); // test hook: 3 << 24 bytes

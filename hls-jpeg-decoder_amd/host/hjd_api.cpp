@@ -172,7 +172,7 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
+    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, seq0, nseq, side_feeds_big, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
@@ -212,6 +212,8 @@ struct hjd_batch {
     uint2 *d_ckpt = nullptr;
     uint2 *d_tkck = nullptr;        // sibling trajectories' checkpoints (small batches)
     uint32_t *d_tkflags = nullptr;
+    uint32_t *d_seqlist = nullptr;   // k_sync_seq: 64 device images per workgroup
+    std::vector<uint32_t> seqlist;
     uint32_t epoch = 0;             // run counter: what a sibling workgroup's flag must show
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
@@ -478,6 +480,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_ckpt);
     (void)hipFree(b->d_tkck);
     (void)hipFree(b->d_tkflags);
+    (void)hipFree(b->d_seqlist);
     (void)hipFree(b->d_dbg);
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
@@ -612,7 +615,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // An image whose whole scan fits one small synchronisation workgroup (with the same warm-up allowance) gets one:
         // k_sync_small, numbered on its own
         im.sync_small = (K < HJD_SYNC_WG_SMALL && im.nsub_cap <= HJD_SYNC_WG_SMALL - K && !getenv("HJD_NO_SMALL_SYNC")) ? 1u : 0u;
-        if (im.sync_small) {
+        // ... and a thumbnail (no restart markers, a scan of at most HJD_SEQ_MAX_BITS) none at all: one lane of k_sync_seq decodes it
+        if (im.sync_small && j.restart_interval <= 0 && (uint64_t)im.scan_len * 8u <= HJD_SEQ_MAX_BITS && !getenv("HJD_NO_SEQ_SYNC")) im.sync_small = 2u;
+        if (im.sync_small == 2u) {
+            im.syncwg0 = 0;
+            im.nsyncwg = 0;
+        } else if (im.sync_small) {
             im.syncwg0 = b->nsyncwg_small;
             im.nsyncwg = 1;
             b->nsyncwg_small += 1;
@@ -731,6 +739,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // k_sync: five word arrays + the u8 marks + 96 words (scratch, block tables), then one staging window per slot (the first
         // 2 x HJD_SYNC_WG words of which double as the work list)
         P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 96 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;
+        P.lds_bytes_sync_seq = (P.lds_state_word_s + 48 + (wpp + 2) * 64) * 4;
         P.lds_bytes_sync_small = (P.lds_state_word_s + 5 * HJD_SYNC_WG_SMALL + HJD_SYNC_WG_SMALL / 4 + 96 + (HJD_SYNC_WG_SMALL / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
         P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + HJD_ENT_CAP + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
@@ -797,7 +806,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         auto fill_sync = [&](uint32_t small) {
             const size_t at = maps.size();
             for (int k = 0; k < b->nimg; k++) {
-                if (b->img[k].sync_small != small) continue;
+                if (b->img[k].sync_small != small || !b->img[k].nsyncwg) continue;
                 if (maps.size() != at + b->img[k].syncwg0) return (size_t)-1;
                 maps.insert(maps.end(), b->img[k].nsyncwg, (uint32_t)k);
             }
@@ -945,6 +954,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 bool have_big = false, have_small = false;
                 for (int q = i0; q < i1; q++) {
                     const HjdImage &im = b->img[q];
+                    if (im.sync_small == 2u) continue; // k_sync_seq: below
                     if (im.sync_small) {
                         if (!have_small) r.ssyncwg0 = im.syncwg0;
                         have_small = true;
@@ -961,6 +971,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 bool have_big = false, have_small = false;
                 for (int q = i0; q < i1; q++) {
                     const HjdImage &im = b->img[q];
+                    if (im.sync_small && !im.write_small) r.side_feeds_big = 1; // synchronised by a small kernel, written by the large one
                     if (im.write_small) {
                         if (!have_small) r.swritewg0 = im.writewg0;
                         have_small = true;
@@ -984,7 +995,31 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             b->ranges.push_back(r);
             i0 = i1;
         }
-        if (b->nsyncwg_small && b->nsyncwg) {
+        {   // k_sync_seq: the thumbnails of every range in groups of 64 that share table set and sampling
+            b->seqlist.clear();
+            for (auto &r : b->ranges) {
+                r.seq0 = (uint32_t)(b->seqlist.size() / 64u);
+                std::map<uint64_t, std::vector<uint32_t>> groups;
+                for (int q = r.i0; q < r.i1; q++)
+                    if (b->img[q].sync_small == 2u) groups[((uint64_t)b->img[q].tabset << 8) | b->img[q].nby].push_back((uint32_t)q);
+                for (auto &kv : groups)
+                    for (size_t at = 0; at < kv.second.size(); at += 64) {
+                        for (size_t t = 0; t < 64; t++) b->seqlist.push_back(at + t < kv.second.size() ? kv.second[at + t] : 0xFFFFFFFFu);
+                    }
+                r.nseq = (uint32_t)(b->seqlist.size() / 64u) - r.seq0;
+            }
+            b->P.seq_list = nullptr;
+            if (!b->seqlist.empty()) {
+                need(slab_reserve(b, b->d_seqlist, sizeof(uint32_t) * b->seqlist.size()));
+                if (rcs != HJD_OK) return rcs;
+                // (pageable source: the copy is staged by the runtime before the call returns)
+                HIPCHK(hipMemcpyAsync(b->d_seqlist, b->seqlist.data(), sizeof(uint32_t) * b->seqlist.size(), hipMemcpyHostToDevice, up));
+                b->P.seq_list = b->d_seqlist;
+            }
+        }
+        bool side_needed = false;
+        for (auto &r : b->ranges) side_needed |= (r.nssyncwg || r.nseq) && r.nsyncwg;
+        if (side_needed) {
             while (b->small_side.size() < b->ranges.size()) {
                 hjd_batch::SideStream ss;
                 HIPCHK(hipStreamCreateWithFlags(&ss.st, hipStreamNonBlocking));
@@ -1172,6 +1207,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     P.off_chunk = r.chunk0;
     P.off_syncwg = r.syncwg0;
     P.off_syncwg_small = r.ssyncwg0;
+    P.off_seqwg = r.seq0;
     P.off_repwg = r.repwg0;
     P.off_writewg = r.writewg0;
     P.off_writewg_small = r.swritewg0;
@@ -1216,18 +1252,22 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         }
         if ((rc = mark("huff_sync"))) return rc;
         // the images with a small workgroup of their own: beside the large ones when the range holds both kinds
-        hjd_batch::SideStream *ss = (r.nssyncwg && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
-        small_write_on_side = ss && nrep == 0; // the small images' final pass follows their synchronisation on the side stream
+        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
+        // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
+        // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
+        // joins before it
+        small_write_on_side = ss && nrep == 0 && !r.side_feeds_big;
         if (ss) {
             if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->st, ss->fork, 0) != hipSuccess) return HJD_ERR_INTERNAL;
             if (hjd_launch_sync(P, r.nssyncwg, 3, ss->st)) return HJD_ERR_INTERNAL;
+            if (hjd_launch_sync_seq(P, r.nseq, ss->st)) return HJD_ERR_INTERNAL;
             if (small_write_on_side && hjd_launch_write(P, r.nswritewg, ss->st, 1)) return HJD_ERR_INTERNAL;
             if (hipEventRecord(ss->done, ss->st) != hipSuccess) return HJD_ERR_INTERNAL;
         }
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
         if (ss && !small_write_on_side) {
             if (hipStreamWaitEvent(s, ss->done, 0) != hipSuccess) return HJD_ERR_INTERNAL;
-        } else if (!ss && hjd_launch_sync(P, r.nssyncwg, 3, s)) {
+        } else if (!ss && (hjd_launch_sync(P, r.nssyncwg, 3, s) || hjd_launch_sync_seq(P, r.nseq, s))) {
             return HJD_ERR_INTERNAL;
         }
         side_done = ss ? ss->done : nullptr;
@@ -1306,6 +1346,8 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.nchunk = b->nchunks;
         all.nsyncwg = b->nsyncwg;
         all.nssyncwg = b->nsyncwg_small;
+        all.nseq = (uint32_t)(b->seqlist.size() / 64u);
+        for (auto &im : b->img) all.side_feeds_big |= (im.sync_small && !im.write_small) ? 1u : 0u;
         all.nrepwg = b->nrepwg;
         all.nwritewg = b->nwritewg;
         all.nswritewg = b->nwritewg_small;

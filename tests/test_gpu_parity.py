@@ -173,6 +173,76 @@ def test_mixed_batch(hjd, dec, golden):
         assert np.array_equal(o, orgb)
 
 
+def test_thumbnail_batches_take_the_small_kernels(hjd):
+    """Images of a few kilobytes: k_sync_seq (one lane decodes a whole scan), k_sync_small / k_write_small (one-wave workgroups) on a
+    side stream beside the large images' kernels.  One batch of 700 thumbnails — five samplings, standard and per-image optimised
+    tables (many table sets: many groups), some with restart markers (which keep the workgroup kinds), sizes on both sides of
+    every threshold — between three large images; every distinct image equals the oracle, with the small kernels and without."""
+    rng = np.random.default_rng(11)
+    samp = [(2, 2), (1, 1), (2, 1), (1, 2), (4, 1)]
+    distinct = []
+    for k in range(60):
+        w, h = int(rng.integers(1, 400)), int(rng.integers(1, 300))
+        hf, vf = samp[k % 5]
+        rgb = T.synth_rgb(w, h, 900 + k, float(rng.choice([2.0, 8.0, 30.0])))
+        mode = T.HUFF_STD if k % 3 else T.HUFF_FOUR_OPTIMISED
+        distinct.append(T.encode_jpeg_ex(rgb, int(rng.choice([35, 85, 97])), hf, vf, 3 if k % 7 == 0 else 0, True, mode))
+    big = [T.synth_jpeg(1920, 1080, 31, 85, 2, 2), T.synth_jpeg(1280, 720, 32, 90, 1, 1), T.synth_jpeg(800, 600, 33, 85, 2, 1, 20, 7.0)]
+    jpgs = [big[0]] + [distinct[k % 60] for k in range(350)] + [big[1]] + [distinct[(k * 7) % 60] for k in range(350)] + [big[2]]
+    want = {}
+    for j in set(jpgs):
+        rc, orgb, _, _, _ = T.oracle_decode(j)
+        want[j] = (rc, orgb)
+    for env in ({}, {"HJD_NO_SEQ_SYNC": "1"}, {"HJD_NO_SEQ_SYNC": "1", "HJD_NO_SMALL_SYNC": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            for streams in (0, 3):
+                d = hjd.Decoder(0, streams=streams)
+                st, outs = d.decode(jpgs)
+                for j, s_, o in zip(jpgs, st, outs):
+                    rc, orgb = want[j]
+                    if rc == 0:
+                        assert s_ == 0 and np.array_equal(o, orgb), (env, streams, len(j))
+                    else:
+                        assert s_ != 0
+                d.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+
+def test_sibling_trajectories_change_nothing_but_the_time(hjd):
+    """Small batches: three further decodes of every subsequence with other block-in-MCU labels (k_sync_sib).  Their checkpoints are
+    hints for the refinement walks; the bytes, the statuses and the absence of host re-synchronisations must not depend on them."""
+    jpgs = [T.synth_jpeg(3840, 2160, 1000, 85, 2, 2), T.synth_jpeg(1920, 1080, 501, 85, 1, 1), T.synth_jpeg(1000, 700, 4243, 90, 2, 1, 25, 9.0),
+            T.encode_jpeg_ex(T.synth_rgb(1600, 1200, 5, 12.0), 80, 2, 2, 0, True, T.HUFF_FOUR_OPTIMISED)]
+    want = [T.oracle_decode(j)[1] for j in jpgs]
+    old = os.environ.get("HJD_SIBLINGS")
+    try:
+        for sib in ("0", "1", "3"):
+            os.environ["HJD_SIBLINGS"] = sib
+            for bits in (0, 1024, 4096):
+                d = hjd.Decoder(0, subseq_bits=bits)
+                b = d.prepare(jpgs)
+                for _ in range(2):  # the second run re-uses the flags of the first (epochs)
+                    b.run()
+                    st = b.finish()
+                assert st == [0] * len(jpgs) and b.resync_count() == 0, (sib, bits, st)
+                for k, w in enumerate(want):
+                    assert np.array_equal(b.download(k), w), (sib, bits, k)
+                b.close()
+                d.close()
+    finally:
+        if old is None:
+            os.environ.pop("HJD_SIBLINGS", None)
+        else:
+            os.environ["HJD_SIBLINGS"] = old
+
+
 @pytest.mark.parametrize("bits", [64, 128, 256, 512, 1024, 4096, 16384])
 def test_subsequence_sizes(hjd, bits, golden):
     """The subsequence length is a tuning knob only: output must not depend on it."""

@@ -76,7 +76,8 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         # --- workgroup counts cover every subsequence under each kernel's tiling
         K = o.sync_overlap
         Q = T_ - K
-        assert K < T_ and o.nsyncwg * Q >= nsub          # k_sync: workgroup w owns [w*Q, (w+1)*Q)
+        seq = o.nsyncwg == 0                             # k_sync_seq: a lane decodes the whole scan (thumbnails without restart markers)
+        assert K < T_ and (o.nsyncwg * Q >= nsub or (seq and scan_len * 8 <= 65536 and not rst))   # k_sync: workgroup w owns [w*Q, (w+1)*Q)
         assert o.nrepwg * T_ >= nsub                     # k_repair
         nph = wps // o.phase_words
         assert o.nwritewg * WW >= nsub * nph             # k_write: one lane per staging window
@@ -91,7 +92,7 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         assert (nph - 1) * nsub + nsub - 1 < nsub * nph <= o.ckpt_entries
         small = K < 64 and nsub <= 64 - K    # one small synchronisation workgroup (k_sync_small): owns from subsequence 0, no warm-up slots, no scratch
         if small:
-            assert o.nsyncwg == 1
+            assert o.nsyncwg == (0 if seq else 1)
         else:
             assert nsub * nph + ((o.nsyncwg - 1) * nph + nph - 1) * K + max(K, 1) - 1 < o.ckpt_entries
         # --- blocks: k_write stores blk[b] for b <= nblocks (closing entry); the IDCT kernel loads blk[b0 + tid], tid <= KB,
