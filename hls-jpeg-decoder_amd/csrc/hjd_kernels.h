@@ -56,7 +56,6 @@ struct HjdParams {
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
     uint32_t phase_words;      // words of a subsequence staged in LDS at a time (power of two, <= subseq_bits / 32)
     uint32_t write_windows;    // staging windows one k_write lane decodes (power of two, <= windows per subsequence)
-    uint32_t lane_warm;        // k_sync round 0: staging windows of the previous subsequence every lane decodes as warm-up
     uint32_t lds_sec_word;     // entropy kernels' dynamic LDS: word offset of the secondary tables
     uint32_t lds_state_word;   //                               word offset of the per-workgroup state arrays
     uint32_t lds_sec_word_s;   // the same two offsets for the synchronisation kernels (their primary tables are twice as large)

@@ -137,8 +137,6 @@ struct hjd_decoder {
     hipEvent_t conc_ev[16] = {};
     uint64_t conc_runs = 0;
     uint32_t write_windows = 1; // staging windows one k_write lane decodes (HJD_WRITE_WINDOWS: tuning knob, power of two)
-    int lane_warm = 0;         // k_sync round 0: warm-up windows per lane inside the previous subsequence; -1 = half a subsequence
-                               // (HJD_LANE_WARM: tuning knob; measured: same work and four windows more latency than none)
     int stagger = 0;           // ranges of a batch run as a software pipeline (batch_enqueue): 0 off, 1 after sync, 2 after the final pass
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
     int conformant = 0;        // hjd_options.conformant: opt-in, outside the parity contract
@@ -388,7 +386,6 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         d->dirty_mode = opt->dirty_mode ? 1 : 0;
         d->conformant = opt->conformant ? 1 : 0;
     }
-    if (const char *ew = getenv("HJD_LANE_WARM")) d->lane_warm = atoi(ew);
     if (const char *ew = getenv("HJD_WRITE_WINDOWS"))
         if (atoi(ew) >= 1 && atoi(ew) <= 64 && (atoi(ew) & (atoi(ew) - 1)) == 0) d->write_windows = (uint32_t)atoi(ew);
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
@@ -728,10 +725,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // staging window of phase_words + 2 words per lane
         P.phase_words = wpp;
         P.write_windows = wwn;
-        {   // warm-up inside the lanes of k_sync's round 0: half a subsequence unless told otherwise
-            const uint32_t nph = (S / 32) / wpp;
-            P.lane_warm = d->lane_warm < 0 ? nph / 2 : ((uint32_t)d->lane_warm > nph ? nph : (uint32_t)d->lane_warm);
-        }
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
