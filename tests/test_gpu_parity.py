@@ -11,6 +11,7 @@ import pytest
 import hjdtools as T
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -484,6 +485,30 @@ def test_large_image(hjd, dec):
     assert st == [0]
     orc, orgb, _, _, _ = T.oracle_decode(data)
     assert orc == 0 and np.array_equal(outs[0], orgb)
+
+
+def test_reference_main_binary_runs_on_the_gpu(hjd, golden, tmp_path):
+    """The drop-in itself: the reference's OWN main.cpp, compiled in the build container and linked against libhjd.so in place of
+    openjpg.cpp / loadjpg.cpp (oracle/Makefile: _ref/refmain_hjd), run here.  main.cpp:28-36 converts ../../../../data/Lenna.jpg
+    into ../../../../data/out.bmp: the file it writes must be the BMP the compiled reference wrote (manifest hash; the two pad
+    bytes per row the reference leaves to the stack are masked on both sides)."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "refmain_hjd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refmain_hjd is built in the build container only (make -C oracle ref)")
+    d, man = golden
+    data = tmp_path / "data"
+    cwd = tmp_path / "a" / "b" / "c" / "d"
+    data.mkdir()
+    cwd.mkdir(parents=True)
+    shutil.copy(os.path.join(d, "Lenna.jpg"), data / "Lenna.jpg")
+    r = subprocess.run([exe], cwd=str(cwd), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bmp = (data / "out.bmp").read_bytes()
+    ent = man["Lenna.jpg"]
+    assert len(bmp) == ent["bmp_bytes"]
+    assert hashlib.sha256(bmp).hexdigest() in (ent["bmp_sha256"], ent.get("bmp_sha256_masked"))
 
 
 def test_reference_shaped_entry_points(hjd, golden):
