@@ -872,8 +872,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     static_assert(MODE == 0 || !SMALL, "the repair kernels have one size");
     // Sibling workgroups (small batches only, HjdParams::tk_n): the grid holds tk_n + 1 workgroups per synchronisation workgroup,
-    // the siblings first.  A sibling decodes round 0 over again with another block-in-MCU label from the second staging window on
-    // and leaves its checkpoints in a slab of its own; see the refinement rounds.
+    // the siblings first.  A sibling decodes round 0 over again from the same guess with another block-in-MCU label and leaves its
+    // checkpoints in a slab of its own; see the refinement rounds.
     static_assert(!SIBS || (MODE == 0 && !SMALL), "siblings: k_sync_sib only");
     const uint32_t TK = SIBS ? P.tk_n : 0u; // (a kernel of its own, k_sync_sib: with the siblings' code merely present k_sync took 5 % longer)
     const uint32_t sib = TK ? TK - blockIdx.x / P.tk_nwg : 0u; // 0 = the workgroup proper
@@ -1012,22 +1012,19 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         for (uint32_t ph = 0; ph < nph; ph++) {
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) phs[c] = ph;
+            if (sib != 0u && ph == 0u) {
+                // A sibling: the same guess with ANOTHER block-in-MCU label (1, 2, 3: for 4:2:0 the other luma blocks).  What a guessed
+                // decode has wrong longest is the block's place in the MCU (it finds the code boundaries within a few hundred
+                // bits); four guesses are four draws.  (Forking the labels from the first guess's state after one staging window,
+                // of the same table class first, was the first form: one 4K image 0.240 ms of k_sync against 0.218 this way.)
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) m[c] = sib % im.nb;
+            }
             decode_windows<(int)C>(E, valid, row, phs, p, z, m, nblk, nrec, mk);
             if (sib != 0u) {
-                // A sibling: the same decode as the workgroup proper through the first window — after it a guessed decode has
-                // nearly always found the code boundaries, and what it still has wrong is the block's place in the MCU — then on
-                // with ANOTHER label (of the same table class first: loadjpg.cpp:945-997 gives the luma blocks of an MCU one
-                // pair of tables, Cb and Cr usually another).  One of the labels is the true one.
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) {
-                    if (ph == 0u) {
-                        const uint32_t nby = im.nby, nb = im.nb, s1 = sib, mm = m[c];
-                        if (mm < nby) m[c] = s1 < nby ? (mm + s1) % nby : min(nby + (s1 - nby), nb - 1u);
-                        else m[c] = s1 == 1u ? (mm == nby ? nby + 1u : nby) : (s1 - 2u) % nby;
-                    } else if (owned[c]) {
-                        *tkck(sib - 1u, ph, sl[c]) = make_uint2(p[c], z[c] | (m[c] << 6) | (nblk[c] << 9) | (nrec[c] << 20));
-                    }
-                }
+                for (uint32_t c = 0; c < C; c++)
+                    if (owned[c]) *tkck(sib - 1u, ph, sl[c]) = make_uint2(p[c], z[c] | (m[c] << 6) | (nblk[c] << 9) | (nrec[c] << 20));
                 continue;
             }
 #pragma unroll
@@ -1323,16 +1320,16 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             for (int c = 0; c < NC; c++) wmk[c] = live[c] ? s_mk0[slot[c]] : 0u; // the walk's marker scan: never behind the state's position, which only grows
             if (!__any(anylive)) return; // waves without work go straight to the barrier
             for (uint32_t step = 0; __any(anylive) && step < 65536u; step++) {
-                uint2 old[NC], sbl[NC][3];
+                uint2 old[NC], sbl[NC][HJD_MAX_SIBLINGS];
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     old[c] = make_uint2(0xFFFFFFFFu, 0u);
                     if (live[c]) old[c] = *ck(ph[c], slot[c]); // arrives while the window is decoded
                     wrow[c] = row0 + slot[c];
 #pragma unroll
-                    for (uint32_t t = 0; t < 3u; t++) { // the siblings' states at this window's end (owned subsequences, from the second window on)
+                    for (uint32_t t = 0; t < HJD_MAX_SIBLINGS; t++) { // the siblings' states at this window's end (owned subsequences)
                         sbl[c][t] = make_uint2(0xFFFFFFFFu, 0u);
-                        if (SIB && live[c] && ((tk_ok >> t) & 1u) && ph[c] != 0u && slot[c] >= nwarm) sbl[c][t] = *tkck(t, ph[c], slot[c]);
+                        if (SIB && live[c] && ((tk_ok >> t) & 1u) && slot[c] >= nwarm) sbl[c][t] = *tkck(t, ph[c], slot[c]);
                     }
                 }
                 decode_windows<NC>(E, live, wrow, ph, p, z, m, nblk, nrec, wmk);
@@ -1350,7 +1347,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     int sibmet = -1; // in step with a sibling's decode instead?
                     if (SIB && !met) {
 #pragma unroll
-                        for (int t = 2; t >= 0; t--)
+                        for (int t = (int)HJD_MAX_SIBLINGS - 1; t >= 0; t--)
                             if (p[c] == sbl[c][t].x && st9 == (sbl[c][t].y & 511u)) sibmet = t;
                     }
                     if (met) {

@@ -24,7 +24,7 @@ struct HjdParams {
                                // private copies for its warm-up slots, per workgroup [window][slot < sync_overlap]
     uint64_t ck_scratch;       // first entry of that scratch area
     // Sibling trajectories (small batches: the chip has room for several decodes of every subsequence).  tk_n sibling workgroups
-    // per synchronisation workgroup repeat round 0 with another block-in-MCU label from the second staging window on; their
+    // per synchronisation workgroup repeat round 0 from the same guess with another block-in-MCU label; their
     // checkpoints (slab t at tk_ckpt + t * tk_stride, canonical layout) are further states a refinement walk may fall into step with.
     uint2 *tk_ckpt;
     uint64_t tk_stride;

@@ -26,7 +26,7 @@ SAMPLINGS = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4)]
 KNOBS = [{}, {"HJD_PHASE_WORDS": "2"}, {"HJD_PHASE_WORDS": "4", "HJD_WRITE_WINDOWS": "2"}, {"HJD_PHASE_WORDS": "8", "HJD_WRITE_WINDOWS": "4"},
          {"HJD_PHASE_WORDS": "32"}, {"HJD_SYNC_OVERLAP": "0"}, {"HJD_SYNC_OVERLAP": "1"}, {"HJD_SYNC_CONC": "0", "HJD_STAGGER": "1"},
          # round 4: sibling trajectories forced on / off, the thumbnails' kernels off one by one
-         {"HJD_SIBLINGS": "3"}, {"HJD_SIBLINGS": "1", "HJD_PHASE_WORDS": "8"}, {"HJD_SIBLINGS": "0"}, {"HJD_NO_SEQ_SYNC": "1"},
+         {"HJD_SIBLINGS": "5"}, {"HJD_SIBLINGS": "2", "HJD_PHASE_WORDS": "8"}, {"HJD_SIBLINGS": "0"}, {"HJD_NO_SEQ_SYNC": "1"},
          {"HJD_NO_SEQ_SYNC": "1", "HJD_NO_SMALL_SYNC": "1"}]
 
 

@@ -217,14 +217,14 @@ def test_thumbnail_batches_take_the_small_kernels(hjd):
 
 
 def test_sibling_trajectories_change_nothing_but_the_time(hjd):
-    """Small batches: three further decodes of every subsequence with other block-in-MCU labels (k_sync_sib).  Their checkpoints are
+    """Small batches: up to five further decodes of every subsequence with the other block-in-MCU labels (k_sync_sib).  Their checkpoints are
     hints for the refinement walks; the bytes, the statuses and the absence of host re-synchronisations must not depend on them."""
     jpgs = [T.synth_jpeg(3840, 2160, 1000, 85, 2, 2), T.synth_jpeg(1920, 1080, 501, 85, 1, 1), T.synth_jpeg(1000, 700, 4243, 90, 2, 1, 25, 9.0),
             T.encode_jpeg_ex(T.synth_rgb(1600, 1200, 5, 12.0), 80, 2, 2, 0, True, T.HUFF_FOUR_OPTIMISED)]
     want = [T.oracle_decode(j)[1] for j in jpgs]
     old = os.environ.get("HJD_SIBLINGS")
     try:
-        for sib in ("0", "1", "3"):
+        for sib in ("0", "1", "3", "5"):
             os.environ["HJD_SIBLINGS"] = sib
             for bits in (0, 1024, 4096):
                 d = hjd.Decoder(0, subseq_bits=bits)
