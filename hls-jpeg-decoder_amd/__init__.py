@@ -25,7 +25,7 @@ EXPORTS = [
     "hjd_parse_header", "hjd_parse_header_ex", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
     "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query", "hjd_debug_sync_profile",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_segment_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query", "hjd_debug_sync_profile",
 ]
 
 
@@ -132,6 +132,8 @@ def lib():
     L.hjd_batch_resync_count.argtypes = [vp]
     L.hjd_batch_sequential_count.restype = ctypes.c_int
     L.hjd_batch_sequential_count.argtypes = [vp]
+    L.hjd_batch_segment_count.restype = ctypes.c_int
+    L.hjd_batch_segment_count.argtypes = [vp]
     L.hjd_decode_batch_host.restype = ctypes.c_int
     L.hjd_decode_batch_host.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), ctypes.c_int,
                                         ctypes.POINTER(vp), ctypes.POINTER(sz), ip]
@@ -334,6 +336,9 @@ class Batch:
 
     def sequential_count(self):
         return lib().hjd_batch_sequential_count(self._h)
+
+    def segment_count(self):
+        return lib().hjd_batch_segment_count(self._h)
 
     def info(self, i):
         w, h = ctypes.c_uint(), ctypes.c_uint()

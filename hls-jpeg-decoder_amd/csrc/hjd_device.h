@@ -123,6 +123,10 @@ struct HjdImage {
                             // 2: none at all — a lane of k_sync_seq decodes the whole scan (thumbnails)
     uint32_t write_small;   // 1: its final-pass workgroups are small ones (k_write_small, their own numbering)
     uint32_t wgsum0;        // first entry of the image in wgsum[] (one array for both kinds of final-pass workgroups)
+    uint32_t seg_cap;       // segment-parallel emulation (hjd_seq.hip): candidates reserved (0: none — the image is left to k_seq_decode),
+    uint32_t seg_off;       //   first entry in seg_pos,
+    uint32_t seg_node;      //   first node ((seg_cap + 1) * nb nodes) in seg_next / seg_w / seg_base / seg_chain
+    uint32_t seg_pad_;
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)
@@ -146,7 +150,7 @@ struct HjdImageState {
     uint32_t sync_decodes;  // diagnostics: subsequence decodes executed by the synchronisation launches
     uint32_t sync_iters_max;
     uint32_t nmarkers;      // restart mode: markers (FF xx, xx != 0) found inside the scan
-    uint32_t emulated;      // 1: the sequential emulation (hjd_seq.hip) has decoded this image in this run
+    uint32_t emulated;      // the emulation (hjd_seq.hip) has decoded this image in this run: 1 = one lane, 2 = parallel over the resynchronisations
 };
 #define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)

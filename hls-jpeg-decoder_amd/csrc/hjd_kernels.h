@@ -51,6 +51,16 @@ struct HjdParams {
     uint32_t lds_bytes_sync_seq;
     const uint32_t *rst_list;  // device images that carry DRI, ascending (the sequential emulation's candidates)
     const uint32_t *rst_groups; // the back-end workgroups (batch-global numbers) of those images: the grid of the gated launch
+    // Segment-parallel emulation (hjd_seq.hip: k_seg_*), images of rst_list with HjdImage::seg_cap != 0:
+    uint32_t nrst;             // entries of rst_list
+    uint32_t *seg_pos;         // candidates (raw byte offsets of FF xx, xx != 00), ascending per image
+    uint32_t *seg_cnt;         // per entry of rst_list: candidates found; all ones = not decoded this way in this run
+    uint32_t *seg_nchain;      // per entry of rst_list: nodes on the true chain
+    uint32_t *seg_plan;        // [2][nrst + 1] exclusive prefixes of the 64-node work items: segment decode, write pass
+    uint32_t *seg_next;        // per node (candidate x block-in-MCU label): next candidate + 1 | label there << 25 | how the segment ended << 29
+    uint4 *seg_w;              // per node: blocks, records, DC differences (Y | Cb << 16, Cr) of its segment
+    uint4 *seg_base;           // per node on the chain: the same sums over everything before it
+    uint32_t *seg_chain;       // per image: the chain's nodes in order
     uint32_t subseq_bits;      // power of two, 64..4096
     uint32_t log2_words;       // log2(subseq_bits / 32)
     uint32_t sync_overlap;     // warm-up subsequences at the front of every synchronisation workgroup
@@ -72,5 +82,6 @@ int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s, int small = 0);
 int hjd_launch_sync_seq(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);
-int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s); // candidates rst_list[first .. first + n): those flagged DIRTY are decoded
+int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s, int after_seg = 0); // candidates rst_list[first .. first + n): those flagged DIRTY are decoded
+int hjd_launch_seg_emulation(const HjdParams &P, hipStream_t s); // the same, parallel over the resynchronisations, for the images with node space
 int hjd_launch_color_table(uint8_t *d_out, hipStream_t s); // test hook: 3 << 24 bytes

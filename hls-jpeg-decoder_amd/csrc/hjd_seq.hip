@@ -1,7 +1,8 @@
 // hjd_seq.hip — the reference's entropy decoder, literally and sequentially (gfx950), for the restart
 // streams on which it leaves the clean-resync domain.
 //   k_seq_decode   ProcessHuffmanBlock + FillNBits with the reference's BYTE-CURSOR rules
-//                  (loadjpg.cpp:446-484, :499-863, :945-997, :1148-1182)
+//                  (loadjpg.cpp:446-484, :499-863, :945-997, :1148-1182), one lane per image
+//   k_seg_*        the same decode, parallel over the places where the reference can resynchronise (below)
 //
 // The parallel path (hjd_entropy.hip) is valid where "jump to the marker at the end of an interval" equals
 // what the reference does.  Where it does not — the resync check fires on a block whose real bits are
@@ -19,6 +20,7 @@
 
 #include "hjd_device.h"
 #include "hjd_kernels.h"
+#include "hjd_kutil.h"
 
 __constant__ uint8_t c_zz_to_slot_seq[64] = HJD_ZZ_TO_SLOT;
 
@@ -93,44 +95,103 @@ __device__ __forceinline__ int seq_extend(uint32_t v, uint32_t n) // DetermineSi
     return v < (1u << (n - 1u)) ? (int)v - (int)((1u << n) - 1u) : (int)v;
 }
 
+typedef uint16_t SeqLut[HJD_LUT_SIZE];
+
+// The image's primary decode tables into LDS (blockDim.x threads; the caller puts a barrier behind it).
+__device__ __forceinline__ void seq_load_lut(SeqLut *s_lut, const HjdTableSet &ts)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(&ts.lut[0][0]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_lut[0][0]);
+    for (uint32_t k = threadIdx.x; k < ts.nlut * (HJD_LUT_SIZE * 2u / 16u); k += blockDim.x) dst[k] = src[k];
+}
+
+// The reference tries the code lengths one after the other (IsInHuffmanCodes over k = 1..16, loadjpg.cpp:562, :713); for the
+// prefix-free tables the parser admits that finds the same (length, symbol) as one look-up of the next 16 bits in the
+// decode tables of the parallel path, and the k FillNBits calls of the search leave the reader where one FillNBits(length)
+// leaves it (each loads at most the one byte that is missing).  So: peek 16 bits on a COPY of the reader, look the code up
+// (11-bit primary table in LDS, secondary in HBM), then consume it with the reader proper.  (Length by length out of LDS
+// the sequential kernel spent 0.9 us per symbol; it is a one-lane chain, so that is its speed.)
+// (length, value bits, zig-zag advance) of the code at the head of the reader's bits, table `ti`; false = no such code
+__device__ __forceinline__ bool seq_peek(const SeqReader &r0, const SeqLut *s_lut, const HjdTableSet &ts, uint32_t ti, uint32_t &len, uint32_t &size,
+                                         uint32_t &adv)
+{
+    SeqReader t = r0;
+    t.fill(16u); // at most two bytes: 16 bits are there afterwards
+    const uint32_t c16 = (t.res >> (t.nbits - 16u)) & 0xFFFFu;
+    uint32_t e = s_lut[ti][c16 >> (16 - HJD_LUT_BITS)];
+    if ((e & 31u) == 0u) {
+        const uint32_t sub = e >> 5;
+        e = sub ? ts.sec[sub - 1u][c16 & (HJD_SEC_SIZE - 1u)] : 0u;
+    }
+    len = e & 31u;
+    size = (e >> 5) & 15u;
+    adv = e >> 9;
+    return len != 0u;
+}
+
+// ONE block as ProcessHuffmanBlock decodes it (loadjpg.cpp:499-863) behind its block-start check, which is the caller's:
+// returns HJD_FLAG_* (0 = decoded).  *diff = the DC difference (0 for a code without extra bits: the predictor stays, :664);
+// nrec counts the block's records on; WRITE stores them (block number b in the record, as k_write does).
+template <bool WRITE>
+__device__ __forceinline__ uint32_t seq_block(SeqReader &r, const SeqLut *s_lut, const HjdTableSet &ts, const HjdImage &im, bool restart, uint32_t comp,
+                                              uint32_t b, int *diff, uint32_t &nrec, uint32_t *rec)
+{
+    const uint32_t tdc = (ts.slot_pack >> (comp * 8u)) & 7u, tac = (ts.slot_pack >> (comp * 8u + 4u)) & 7u;
+    *diff = 0;
+    {
+        uint32_t len, size, adv;
+        // :562: DC codes of 1..15 bits.  No match: the reference prints and carries on with the AC loop on the same bits
+        // (:680-685): not emulated
+        if (!seq_peek(r, s_lut, ts, tdc, len, size, adv) || len > 15u) return HJD_FLAG_BAD_CODE;
+        r.skip(len);
+        if (size != 0u) {
+            if (restart && r.on_marker()) r.resync(); // between the code and its extra bits, :631-640
+            *diff = (int)(int16_t)seq_extend(r.get(size), size);
+        }
+    }
+    uint32_t nr = 1;
+    bool eob = false;
+    while (nr <= 63u && !eob) { // :700
+        uint32_t len, size, adv;
+        if (!seq_peek(r, s_lut, ts, tac, len, size, adv)) return HJD_FLAG_BAD_CODE; // no code of 1..16 bits: the reference's loop makes no progress
+        r.skip(len);
+        if (size == 0u) { // :768-775: adv = 64 end of block, 16 ZRL, 0 any other run with size 0 (ignored)
+            if (adv == 64u) eob = true;
+            else if (adv == 16u) nr += 16u;
+            else if (r.idx > im.scan_len + 4u) return HJD_FLAG_BAD_CODE; // an ignored symbol decoded from the zeros past the end: the
+                                                                         // reference repeats it forever
+        } else {
+            nr += adv - 1u; // run, :778
+            if (nr > 63u) return HJD_FLAG_OVERRUN; // the reference writes DCT[nr] out of bounds here (:780-806)
+            const int data = (int)(int16_t)seq_extend(r.get(size), size);
+            if (WRITE) {
+                if (nrec >= im.rec_cap) return HJD_FLAG_OVERRUN;
+                rec[nrec] = ((uint32_t)data & 0xFFFFu) | ((uint32_t)c_zz_to_slot_seq[nr] << 16) | ((b & 127u) << 22);
+            }
+            nrec++;
+            nr++;
+        }
+    }
+    return 0u;
+}
+
+__device__ __forceinline__ uint32_t seq_comp(const HjdImage &im, uint32_t m) { return m < im.nby ? 0u : m - im.nby + 1u; } // DecodeMCU order, :945-997
+
 // One workgroup per image with DRI; it returns at once unless the parallel path has flagged the image (the launch is part of
 // every run of a batch that holds such images, on a side stream: no host round trip, no allocation — hjd_api.cpp).
-__global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
+// after_seg: launched behind the segment-parallel emulation below — what that one has decoded is left alone.
+__global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, uint32_t after_seg)
 {
-    // The reference tries the code lengths one after the other (IsInHuffmanCodes over k = 1..16, loadjpg.cpp:562, :713); for the
-    // prefix-free tables the parser admits that finds the same (length, symbol) as one look-up of the next 16 bits in the
-    // decode tables of the parallel path, and the k FillNBits calls of the search leave the reader where one FillNBits(length)
-    // leaves it (each loads at most the one byte that is missing).  So: peek 16 bits on a COPY of the reader, look the code up
-    // (11-bit primary table in LDS, secondary in HBM), then consume it with the reader proper.  (Length by length out of LDS
-    // this kernel spent 0.9 us per symbol; it is a one-lane chain, so that is its speed.)
-    __shared__ uint16_t s_lut[HJD_SLOTS][HJD_LUT_SIZE];
+    __shared__ SeqLut s_lut[HJD_SLOTS];
     const int ii = (int)P.rst_list[first + blockIdx.x];
     if (!(P.st[ii].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER))) return; // whatever else the parallel path flagged after leaving
                                                                             // the clean-resync domain means nothing
+    if (after_seg && P.st[ii].emulated) return;
     const HjdImage &im = P.img[ii];
     const HjdTableSet &ts = P.tabs[im.tabset];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(&ts.lut[0][0]);
-        uint4 *dst = reinterpret_cast<uint4 *>(&s_lut[0][0]);
-        for (uint32_t k = threadIdx.x; k < ts.nlut * (HJD_LUT_SIZE * 2u / 16u); k += 64u) dst[k] = src[k];
-    }
+    seq_load_lut(s_lut, ts);
     __syncthreads();
     if (threadIdx.x != 0) return;
-    // (length, value bits, zig-zag advance) of the code at the head of the reader's bits, table `ti`; false = no such code
-    auto peek_code = [&](const SeqReader &r0, uint32_t ti, uint32_t &len, uint32_t &size, uint32_t &adv) -> bool {
-        SeqReader t = r0;
-        t.fill(16u); // at most two bytes: 16 bits are there afterwards
-        const uint32_t c16 = (t.res >> (t.nbits - 16u)) & 0xFFFFu;
-        uint32_t e = s_lut[ti][c16 >> (16 - HJD_LUT_BITS)];
-        if ((e & 31u) == 0u) {
-            const uint32_t sub = e >> 5;
-            e = sub ? ts.sec[sub - 1u][c16 & (HJD_SEC_SIZE - 1u)] : 0u;
-        }
-        len = e & 31u;
-        size = (e >> 5) & 15u;
-        adv = e >> 9;
-        return len != 0u;
-    };
     SeqReader r;
     r.s = P.raw + im.raw_off;
     r.n = im.scan_len;
@@ -143,62 +204,15 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
     const bool restart = im.restart != 0;
 
     for (uint32_t b = 0; b < im.nblocks && !flags; b++) {
-        const uint32_t m = b % im.nb;
-        const uint32_t comp = m < im.nby ? 0u : m - im.nby + 1u; // DecodeMCU order, :945-997
-        const uint32_t tdc = (ts.slot_pack >> (comp * 8u)) & 7u, tac = (ts.slot_pack >> (comp * 8u + 4u)) & 7u;
-        const uint32_t first = nrec;
-
+        const uint32_t comp = seq_comp(im, b % im.nb);
+        const uint32_t first_rec = nrec;
         if (restart && r.on_marker()) r.resync(); // block-start check, :535-550
-
-        int dc = prev[comp];
-        {
-            uint32_t len, size, adv;
-            // :562: DC codes of 1..15 bits.  No match: the reference prints and carries on with the AC loop on the same bits
-            // (:680-685): not emulated
-            if (!peek_code(r, tdc, len, size, adv) || len > 15u) {
-                flags |= HJD_FLAG_BAD_CODE;
-                break;
-            }
-            r.skip(len);
-            if (size != 0u) {
-                if (restart && r.on_marker()) r.resync(); // between the code and its extra bits, :631-640
-                const int data = (int)(int16_t)seq_extend(r.get(size), size);
-                dc = (int)(int16_t)(data + prev[comp]); // :664
-                prev[comp] = dc;
-            }
-        }
-
-        uint32_t nr = 1;
-        bool eob = false;
-        while (nr <= 63u && !eob) { // :700
-            uint32_t len, size, adv;
-            if (!peek_code(r, tac, len, size, adv)) { // no code of 1..16 bits: the reference's loop makes no progress
-                flags |= HJD_FLAG_BAD_CODE;
-                break;
-            }
-            r.skip(len);
-            if (size == 0u) { // :768-775: adv = 64 end of block, 16 ZRL, 0 any other run with size 0 (ignored)
-                if (adv == 64u) eob = true;
-                else if (adv == 16u) nr += 16u;
-                else if (r.idx > im.scan_len + 4u) flags |= HJD_FLAG_BAD_CODE; // an ignored symbol decoded from the zeros past
-                                                                               // the end: the reference repeats it forever
-            } else {
-                nr += adv - 1u; // run, :778
-                if (nr > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806)
-                    flags |= HJD_FLAG_OVERRUN;
-                    break;
-                }
-                const int data = (int)(int16_t)seq_extend(r.get(size), size);
-                const uint32_t slot = c_zz_to_slot_seq[nr];
-                if (nrec < im.rec_cap) rec[nrec] = ((uint32_t)data & 0xFFFFu) | (slot << 16) | ((b & 127u) << 22);
-                else flags |= HJD_FLAG_OVERRUN;
-                nrec++;
-                nr++;
-            }
-            if (flags) break;
-        }
-        blk[b] = make_uint2(first, 0u); // the back end takes the predicted DC from dca[], the slots its records fill from the records
-        dca[b] = (int16_t)dc;
+        int diff;
+        flags |= seq_block<true>(r, s_lut, ts, im, restart, comp, b, &diff, nrec, rec);
+        if (flags) break;
+        prev[comp] = (int)(int16_t)(diff + prev[comp]); // :664
+        blk[b] = make_uint2(first_rec, 0u); // the back end takes the predicted DC from dca[], the slots its records fill from the records
+        dca[b] = (int16_t)prev[comp];
     }
     blk[im.nblocks] = make_uint2(min(nrec, im.rec_cap), 0u);
     HjdImageState &st = P.st[ii];
@@ -209,10 +223,317 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first)
     st.emulated = 1u;
 }
 
-int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s)
+// ---- the same emulation, parallel over the resynchronisations ----------------------------------------------------------------
+// After a resync at a block start the reference's reader is in a KNOWN state: cursor = marker + 2, reservoir empty
+// (loadjpg.cpp:544-546).  What is not known without the decode up to there is the block it believes it is in.  So every
+// place the check can fire — a raw byte FF followed by a byte that is not 00: a CANDIDATE — is a segment start, and a segment is
+// decoded under each of the nb block-in-MCU labels by a lane of its own (node = candidate x label; node 0 = the start of the
+// scan, label 0) until ITS block-start check fires: that names the next candidate, the label there is (label + blocks) mod nb.
+// The true decode is the chain of nodes from node 0; one lane per image follows it (out of LDS) and adds up blocks, records and
+// DC differences, then the chain's nodes are decoded once more, in parallel, this time writing records, block entries and
+// predicted DC at their places.  A resync between a DC code and its extra bits (:631-640) does not end a segment: the lane
+// carries on through it as the reference does.  Nodes are cut off after seg_cap_blocks() blocks (a wrong label may run through
+// many markers); when the TRUE chain meets a cut-off node, or the candidates outnumber the space reserved, the image is left
+// to k_seq_decode.
+#define SEG_RESYNC 0u
+#define SEG_ERR 1u
+#define SEG_EOD 2u
+#define SEG_CUT 3u
+#define SEG_DEAD 4u
+#define SEG_NONE 0xFFFFFFFFu
+#define SEG_TILE 3072u // nodes of a chain tile in LDS
+
+__device__ __forceinline__ uint32_t seg_cap_blocks(const HjdImage &im) { return max(256u, 2u * im.ri_blocks + 64u); }
+
+// candidates of one image, ascending; grid = the images with DRI
+__global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
+{
+    __shared__ uint32_t s_w[17];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const int ii = (int)P.rst_list[q];
+    const HjdImage &im = P.img[ii];
+    const bool want = (P.st[ii].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) && im.seg_cap != 0u;
+    if (!want) {
+        if (tid == 0) P.seg_cnt[q] = SEG_NONE, P.seg_nchain[q] = 0u;
+        return;
+    }
+    if (tid == 0) P.st[ii].emulated = 0u; // a host re-synchronisation runs this again
+    const uint8_t *raw = P.raw + im.raw_off;
+    const uint32_t n = im.scan_len;
+    uint32_t *pos = P.seg_pos + im.seg_off;
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n; base += 256u * 16u) { // uniform
+        const uint32_t o = base + tid * 16u;
+        uint32_t w[5] = {0u, 0u, 0u, 0u, 0u};
+        if (o < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(raw + o); // the slab is 16-byte aligned and padded
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+            if (o + 16u < n) w[4] = raw[o + 16u];
+        }
+        uint32_t mask = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint32_t c = (w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu, d = (w[(k + 1u) >> 2] >> (((k + 1u) & 3u) * 8u)) & 0xFFu;
+            if (c == 0xFFu && d != 0u && o + k + 1u < n) mask |= 1u << k; // SeqReader::on_marker: bytes past the end read as 00
+        }
+        uint32_t sum;
+        uint32_t at = total + block_excl_scan(__popc(mask), s_w, &sum);
+        while (mask) {
+            const uint32_t k = __ffs(mask) - 1u;
+            mask &= mask - 1u;
+            if (at < im.seg_cap) pos[at] = o + k;
+            at++;
+        }
+        total += sum;
+    }
+    if (tid == 0) P.seg_cnt[q] = total <= im.seg_cap ? total : SEG_NONE, P.seg_nchain[q] = 0u;
+}
+
+// exclusive prefix of the images' 64-node work items: which 0 = segments (all nodes), 1 = the write pass (the chain's nodes)
+__global__ __launch_bounds__(256) void k_seg_plan(HjdParams P, uint32_t which)
+{
+    __shared__ uint32_t s_w[17];
+    uint32_t *plan = P.seg_plan + (size_t)which * (P.nrst + 1u);
+    uint32_t run = 0;
+    for (uint32_t q0 = 0; q0 < P.nrst; q0 += 256u) {
+        const uint32_t q = q0 + threadIdx.x;
+        uint32_t items = 0;
+        if (q < P.nrst) {
+            if (which == 0u) {
+                const uint32_t c = P.seg_cnt[q];
+                if (c != SEG_NONE) items = ((c + 1u) * P.img[P.rst_list[q]].nb + 63u) / 64u;
+            } else items = (P.seg_nchain[q] + 63u) / 64u;
+        }
+        uint32_t sum;
+        const uint32_t ex = run + block_excl_scan(items, s_w, &sum);
+        if (q < P.nrst) plan[q] = ex;
+        run += sum;
+    }
+    if (threadIdx.x == 0) plan[P.nrst] = run;
+}
+
+// work item -> (entry of rst_list, chunk of 64 nodes): the last q with plan[q] <= item
+__device__ __forceinline__ uint32_t seg_find(const uint32_t *plan, uint32_t nrst, uint32_t item)
+{
+    uint32_t lo = 0, hi = nrst - 1u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (plan[mid] <= item) lo = mid;
+        else hi = mid - 1u;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void seg_start(SeqReader &r, const HjdParams &P, const HjdImage &im, uint32_t j)
+{
+    r.s = P.raw + im.raw_off;
+    r.n = im.scan_len;
+    r.idx = j ? P.seg_pos[im.seg_off + (j - 1u)] + 2u : 0u; // behind the resync at candidate j - 1; node 0: the start of the scan
+    r.res = r.nbits = 0u;
+}
+
+// every node's segment, counted: a persistent grid over the work items of k_seg_plan(0) (none: every workgroup returns at once)
+__global__ __launch_bounds__(64) void k_seg_decode(HjdParams P)
+{
+    __shared__ SeqLut s_lut[HJD_SLOTS];
+    const uint32_t *plan = P.seg_plan;
+    const uint32_t total = plan[P.nrst];
+    uint32_t have = 0xFFFFFFFFu; // table set in LDS
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) { // uniform
+        const uint32_t q = seg_find(plan, P.nrst, item);
+        const int ii = (int)P.rst_list[q];
+        const HjdImage &im = P.img[ii];
+        const HjdTableSet &ts = P.tabs[im.tabset];
+        if (have != im.tabset) {
+            __syncthreads();
+            seq_load_lut(s_lut, ts);
+            have = im.tabset;
+            __syncthreads();
+        }
+        const uint32_t cnt = P.seg_cnt[q], node = (item - plan[q]) * 64u + threadIdx.x;
+        if (node >= (cnt + 1u) * im.nb) continue;
+        const uint32_t j = node / im.nb, m0 = node % im.nb;
+        uint32_t kind = SEG_DEAD, nblk = 0, nrec = 0, dc[3] = {0u, 0u, 0u}, nextpos = 0;
+        if (j != 0u || m0 == 0u) {
+            SeqReader r;
+            seg_start(r, P, im, j);
+            bool check = j == 0u; // a node behind a resync starts behind the check (the reference checks once per block, :535)
+            const uint32_t cap = seg_cap_blocks(im);
+            for (;;) {
+                if (check && r.on_marker()) {
+                    kind = SEG_RESYNC;
+                    nextpos = r.idx;
+                    break;
+                }
+                check = true;
+                if (nblk >= cap) {
+                    kind = SEG_CUT;
+                    break;
+                }
+                if (r.idx > im.scan_len + 8u) { // in the zeros past the end: no check fires any more
+                    kind = SEG_EOD;
+                    break;
+                }
+                const uint32_t comp = seq_comp(im, (m0 + nblk) % im.nb);
+                int diff;
+                if (seq_block<false>(r, s_lut, ts, im, true, comp, 0u, &diff, nrec, nullptr)) {
+                    kind = SEG_ERR;
+                    break;
+                }
+                dc[comp] += (uint32_t)diff;
+                nblk++;
+            }
+        }
+        uint32_t nxt = 0;
+        if (kind == SEG_RESYNC) { // the candidate at nextpos: it is one, by the rule of k_seg_list
+            const uint32_t *pos = P.seg_pos + im.seg_off;
+            uint32_t lo = 0, hi = cnt - 1u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pos[mid] < nextpos) lo = mid + 1u;
+                else hi = mid;
+            }
+            nxt = lo + 1u;
+        }
+        P.seg_next[im.seg_node + node] = nxt | (((m0 + nblk) % im.nb) << 25) | (kind << 29);
+        P.seg_w[im.seg_node + node] = make_uint4(nblk, nrec, (dc[0] & 0xFFFFu) | (dc[1] << 16), dc[2] & 0xFFFFu);
+    }
+}
+
+// the true chain of one image: grid = the images with DRI.  One lane walks, tile by tile out of LDS; per node on the chain
+// seg_base = (blocks, records before it, DC predictors there), seg_chain = the nodes in order.
+__global__ __launch_bounds__(256) void k_seg_chain(HjdParams P)
+{
+    __shared__ uint32_t s_next[SEG_TILE];
+    __shared__ uint4 s_wt[SEG_TILE];
+    __shared__ uint32_t s_j, s_stop;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t cnt = P.seg_cnt[q];
+    if (cnt == SEG_NONE) return;
+    const int ii = (int)P.rst_list[q];
+    const HjdImage &im = P.img[ii];
+    const uint32_t nb = im.nb, tile = SEG_TILE / nb; // candidates per tile
+    const uint32_t *gnext = P.seg_next + im.seg_node;
+    const uint4 *gw = P.seg_w + im.seg_node;
+    uint4 *gbase = P.seg_base + im.seg_node;
+    uint32_t *gchain = P.seg_chain + im.seg_node;
+    uint32_t j = 0, m = 0, b = 0, nrec = 0, d0 = 0, d1 = 0, d2 = 0, nchain = 0; // lane 0's
+    bool failed = false;
+    if (tid == 0) s_j = 0u, s_stop = 0u;
+    __syncthreads();
+    for (;;) { // uniform: s_j / s_stop
+        const uint32_t t0 = s_j;
+        if (s_stop) break;
+        const uint32_t n0 = t0 * nb, n1 = min(t0 + tile, cnt + 1u) * nb;
+        for (uint32_t k = n0 + tid; k < n1; k += 256u) s_next[k - n0] = gnext[k], s_wt[k - n0] = gw[k];
+        __syncthreads();
+        if (tid == 0) {
+            bool stop = false;
+            while (!stop && j < t0 + tile) {
+                const uint32_t node = j * nb + m;
+                const uint32_t nx = s_next[node - n0];
+                const uint4 w = s_wt[node - n0];
+                const uint32_t kind = nx >> 29;
+                if (kind == SEG_CUT || kind == SEG_DEAD) {
+                    failed = stop = true;
+                    break;
+                }
+                gbase[node] = make_uint4(b, nrec, (d0 & 0xFFFFu) | (d1 << 16), d2 & 0xFFFFu);
+                gchain[nchain++] = node;
+                b += w.x;
+                nrec += w.y;
+                d0 += w.z & 0xFFFFu, d1 += w.z >> 16, d2 += w.w;
+                if (kind != SEG_RESYNC || b >= im.nblocks) stop = true; // an error or the end of the data: that node's lane in the write pass sees to it
+                j = nx & 0x1FFFFFFu;
+                m = (nx >> 25) & 15u;
+            }
+            s_j = j;
+            s_stop = stop ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.seg_nchain[q] = failed ? 0u : nchain;
+        if (!failed) {
+            HjdImageState &st = P.st[ii];
+            st.flags &= HJD_FLAG_BAD_MARKER; // as k_seq_decode: the write pass adds what the true decode runs into
+            st.total_blocks = im.nblocks;
+            st.emulated = 2u;
+        }
+    }
+}
+
+// the chain's nodes once more, writing: a persistent grid over the work items of k_seg_plan(1)
+__global__ __launch_bounds__(64) void k_seg_write(HjdParams P)
+{
+    __shared__ SeqLut s_lut[HJD_SLOTS];
+    const uint32_t *plan = P.seg_plan + (P.nrst + 1u);
+    const uint32_t total = plan[P.nrst];
+    uint32_t have = 0xFFFFFFFFu;
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) { // uniform
+        const uint32_t q = seg_find(plan, P.nrst, item);
+        const int ii = (int)P.rst_list[q];
+        const HjdImage &im = P.img[ii];
+        const HjdTableSet &ts = P.tabs[im.tabset];
+        if (have != im.tabset) {
+            __syncthreads();
+            seq_load_lut(s_lut, ts);
+            have = im.tabset;
+            __syncthreads();
+        }
+        const uint32_t k = (item - plan[q]) * 64u + threadIdx.x;
+        if (k >= P.seg_nchain[q]) continue;
+        const uint32_t node = P.seg_chain[im.seg_node + k];
+        const uint4 base = P.seg_base[im.seg_node + node];
+        const uint32_t j = node / im.nb, m0 = node % im.nb, b0 = base.x;
+        SeqReader r;
+        seg_start(r, P, im, j);
+        uint32_t *rec = P.rec + im.rec_off;
+        uint2 *blk = P.blk + im.blk_off;
+        int16_t *dca = P.dca + im.blk_off;
+        int prev[3] = {(int)(int16_t)(base.z & 0xFFFFu), (int)(int16_t)(base.z >> 16), (int)(int16_t)(base.w & 0xFFFFu)};
+        uint32_t b = b0, nrec = base.y, flags = 0;
+        bool check = j == 0u;
+        while (b < im.nblocks) {
+            if (check && r.on_marker()) break; // the next node of the chain starts here
+            check = true;
+            const uint32_t comp = seq_comp(im, (m0 + (b - b0)) % im.nb);
+            const uint32_t first_rec = nrec;
+            int diff;
+            flags = seq_block<true>(r, s_lut, ts, im, true, comp, b, &diff, nrec, rec);
+            if (flags) break;
+            prev[comp] = (int)(int16_t)(diff + prev[comp]);
+            blk[b] = make_uint2(first_rec, 0u);
+            dca[b] = (int16_t)prev[comp];
+            b++;
+        }
+        if (flags) { // the true decode fails here, before its last block: k_seq_decode's verdict
+            atomicOr(&P.st[ii].flags, flags);
+            P.st[ii].total_blocks = 0u;
+        } else if (b == im.nblocks) blk[im.nblocks] = make_uint2(min(nrec, im.rec_cap), 0u);
+    }
+}
+
+int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStream_t s, int after_seg)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_seq_decode, dim3(n), dim3(64), 0, s, P, first);
+    hipLaunchKernelGGL(k_seq_decode, dim3(n), dim3(64), 0, s, P, first, (uint32_t)after_seg);
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : (int)e_;
+}
+
+// The segment-parallel emulation of every flagged image of rst_list that has node space (HjdImage::seg_cap); six launches, all
+// of them gated on the device: for clean restart streams the first two return at once and the persistent grids find no work.
+int hjd_launch_seg_emulation(const HjdParams &P, hipStream_t s)
+{
+    if (!P.nrst) return 0;
+    const uint32_t grid = 4096u; // 64-lane workgroups: as many as the chip holds at once
+    hipLaunchKernelGGL(k_seg_list, dim3(P.nrst), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 0u);
+    hipLaunchKernelGGL(k_seg_decode, dim3(grid), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(k_seg_chain, dim3(P.nrst), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 1u);
+    hipLaunchKernelGGL(k_seg_write, dim3(grid), dim3(64), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

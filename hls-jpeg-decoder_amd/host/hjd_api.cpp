@@ -177,7 +177,8 @@ struct hjd_batch {
     std::vector<hipEvent_t> stagger_ev; // per range: recorded after its synchronisation (or final pass), the next range waits for it
     hipEvent_t fork_ev = nullptr;
     int resyncs = 0;                 // host-driven re-synchronisation rounds since prepare (0 in normal operation)
-    int dirty_decodes = 0;           // images decoded by the sequential emulation kernel since prepare
+    int dirty_decodes = 0;           // images decoded by the emulation kernels (hjd_seq.hip) since prepare
+    int segment_decodes = 0;         // ... of those, parallel over the resynchronisations (k_seg_*)
     // Restart streams outside the clean-resync domain: every run ends with a launch of k_seq_decode over the images that carry
     // DRI (it returns at once for those the parallel path did not flag) and a gated launch of the back end, on a side stream
     // that waits for the run and that hjd_batch_finish waits for.  Nothing is allocated and no host round trip is needed.
@@ -211,6 +212,8 @@ struct hjd_batch {
     uint2 *d_tkck = nullptr;        // sibling trajectories' checkpoints (small batches)
     uint32_t *d_tkflags = nullptr;
     uint32_t *d_seqlist = nullptr;   // k_sync_seq: 64 device images per workgroup
+    uint8_t *d_seg = nullptr;        // segment-parallel emulation: candidates, nodes, plans (one slab, carved up in batch_build)
+    size_t seg_npos = 0, seg_nnodes = 0;
     std::vector<uint32_t> seqlist;
     uint32_t epoch = 0;             // run counter: what a sibling workgroup's flag must show
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
@@ -478,6 +481,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_tkck);
     (void)hipFree(b->d_tkflags);
     (void)hipFree(b->d_seqlist);
+    (void)hipFree(b->d_seg);
     (void)hipFree(b->d_dbg);
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
@@ -530,7 +534,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->nwritewg_small = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
-    b->dirty_decodes = 0;
+    b->dirty_decodes = b->segment_decodes = 0;
     DeviceGuard guard(b->dry ? -1 : d->device);
     if (!guard.ok) return HJD_ERR_NO_DEVICE;
     if (b->seq_pending) { // the previous contents' sequential emulation (side stream) still owns the slabs
@@ -707,6 +711,26 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->rst_images.clear();
     for (int k = 0; k < b->nimg; k++)
         if (b->img[k].restart) b->rst_images.push_back((uint32_t)k);
+    {   // Node space of the segment-parallel emulation (hjd_seq.hip: candidates x block-in-MCU labels, 40 bytes a node), in image
+        // order until the budget is spent; an image without any is left to the one-lane kernel.  HJD_NO_SEG_EMULATION=1: test knob.
+        size_t pos_cur = 0, node_cur = 0;
+        const size_t budget = (size_t)16 << 20;
+        const bool off = getenv("HJD_NO_SEG_EMULATION") != nullptr || d->dirty_mode != 0;
+        for (uint32_t q : b->rst_images) {
+            HjdImage &im = b->img[q];
+            const uint32_t cap = im.mark_cap + im.n_rst / 8u; // a well-formed scan holds n_rst of them
+            const size_t nodes = (size_t)(cap + 1u) * im.nb;
+            im.seg_cap = im.seg_off = im.seg_node = im.seg_pad_ = 0u;
+            if (off || node_cur + nodes > budget || cap >= (1u << 24)) continue;
+            im.seg_cap = cap;
+            im.seg_off = (uint32_t)pos_cur;
+            im.seg_node = (uint32_t)node_cur;
+            pos_cur += cap;
+            node_cur += nodes;
+        }
+        b->seg_npos = pos_cur;
+        b->seg_nnodes = node_cur;
+    }
     b->seq_pending = false;
     b->raw_bytes = raw_cur;
     b->ustream_bytes = us_cur;
@@ -782,6 +806,10 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 HIPCHK(hipMemsetAsync(b->d_tkflags, 0, b->cap[(const void *)&b->d_tkflags], up));
             }
         }
+    }
+    {
+        const size_t nrst = b->rst_images.size(), words = b->seg_npos + 2 * nrst + 2 * (nrst + 1) + 2 * b->seg_nnodes + 8;
+        if (b->seg_nnodes) need(slab_reserve(b, b->d_seg, 2 * sizeof(uint4) * b->seg_nnodes + sizeof(uint32_t) * words));
     }
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
@@ -911,6 +939,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.ckpt = b->d_ckpt;
     P.tk_ckpt = b->d_tkck;
     P.tk_flags = b->d_tkflags;
+    P.nrst = b->seg_nnodes ? (uint32_t)b->rst_images.size() : 0u; // 0: no segment-parallel emulation in this batch
+    if (b->seg_nnodes) {
+        const size_t nrst = b->rst_images.size();
+        P.seg_w = reinterpret_cast<uint4 *>(b->d_seg);
+        P.seg_base = P.seg_w + b->seg_nnodes;
+        P.seg_next = reinterpret_cast<uint32_t *>(P.seg_base + b->seg_nnodes);
+        P.seg_chain = P.seg_next + b->seg_nnodes;
+        P.seg_pos = P.seg_chain + b->seg_nnodes;
+        P.seg_cnt = P.seg_pos + b->seg_npos;
+        P.seg_nchain = P.seg_cnt + nrst;
+        P.seg_plan = P.seg_nchain + nrst;
+    }
     P.dbg = nullptr;
     if (getenv("HJD_SYNC_PROF")) {
         need(slab_reserve(b, b->d_dbg, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1)));
@@ -1306,7 +1346,9 @@ static int emulation_enqueue(hjd_batch *b, hipStream_t s)
     if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_stream) return HJD_OK;
     HIPCHK(hipEventRecord(b->seq_fork, s));
     HIPCHK(hipStreamWaitEvent(b->seq_stream, b->seq_fork, 0));
-    if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream)) return HJD_ERR_INTERNAL;
+    // parallel over the resynchronisations where the image has node space; the one-lane kernel takes what that leaves
+    if (hjd_launch_seg_emulation(b->P, b->seq_stream)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream, b->P.nrst != 0u)) return HJD_ERR_INTERNAL;
     {   // the back end again, over the candidates' workgroups only (round 3 launched the whole span from the first to the last
         // candidate: a batch with restart streams at both ends ran a million workgroups that returned at once)
         HjdParams P = b->P;
@@ -1510,7 +1552,7 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
         }
     }
     if (emulation_ran)
-        for (uint32_t q : b->rst_images) b->dirty_decodes += b->state[q].emulated ? 1 : 0;
+        for (uint32_t q : b->rst_images) b->dirty_decodes += b->state[q].emulated ? 1 : 0, b->segment_decodes += b->state[q].emulated == 2u ? 1 : 0;
     for (int i = 0; i < b->n; i++) {
         int st = b->parse_status[i];
         const int di = b->dev_index[i];
@@ -1619,6 +1661,7 @@ extern "C" int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, siz
 
 extern "C" int hjd_batch_resync_count(const hjd_batch *b) { return b ? b->resyncs : -1; }
 extern "C" int hjd_batch_sequential_count(const hjd_batch *b) { return b ? b->dirty_decodes : -1; }
+extern "C" int hjd_batch_segment_count(const hjd_batch *b) { return b ? b->segment_decodes : -1; }
 
 extern "C" int hjd_batch_totals(const hjd_batch *b, uint64_t *pixels, uint64_t *alg, uint64_t *scan)
 {

@@ -187,6 +187,9 @@ int hjd_batch_resync_count(const hjd_batch *b);
  * clean-resync domain) in the runs finished since prepare / reset.  The emulation is enqueued by hjd_batch_run itself, on a
  * side stream: statuses and outputs of such images are final after hjd_batch_finish. */
 int hjd_batch_sequential_count(const hjd_batch *b);
+/* ... and how many of those were decoded in parallel over the places where the reference resynchronises (csrc/hjd_seq.hip: k_seg_*)
+ * rather than by one lane per image. */
+int hjd_batch_segment_count(const hjd_batch *b);
 
 /* A batch object that can be prepared again and again in place: slabs and pinned staging are re-allocated only
  * when new contents need more than they hold.  hjd_batch_reset = the work of hjd_batch_prepare on an existing

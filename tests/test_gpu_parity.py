@@ -364,6 +364,55 @@ def test_restart_synthetic_matches_oracle_or_is_refused(hjd, dec, w, h, hf, vf, 
         assert st[0] == hjd.HJD_ERR_CORRUPT, (st, orc)
 
 
+def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
+    """Restart streams outside the clean-resync domain: the emulation runs parallel over the places where the
+    reference can resynchronise (csrc/hjd_seq.hip: k_seg_*), one lane per (candidate, block-in-MCU label); the one-lane kernel
+    stays as the fallback (HJD_NO_SEG_EMULATION=1 forces it).  Both must give the oracle's bytes, or both the oracle's refusal."""
+    specs = [(320, 240, 1, 1, 2, 0.5, 4105), (320, 240, 1, 1, 3, 2.0, 4110), (320, 240, 2, 1, 1, 4.0, 4119), (320, 240, 1, 2, 3, 4.0, 4159),
+             (250, 187, 2, 1, 3, 0.5, 4205), (250, 187, 4, 1, 3, 0.5, 4253), (512, 384, 1, 1, 2, 0.5, 4265), (512, 384, 2, 1, 7, 0.5, 4289),
+             (512, 384, 2, 2, 2, 4.0, 4299), (512, 384, 1, 2, 2, 2.0, 4314), (512, 384, 2, 1, 2, 0.5, 4281), (250, 187, 1, 1, 1, 0.5, 4181),
+             (1920, 1080, 2, 1, 1, 7.0, 4103), (640, 480, 2, 2, 1, 6.0, 4100), (256, 256, 2, 2, 5, 0.5, 4102)]   # found by search: up to 1895 early resyncs, 12 between a DC code and its bits; two the reference cannot decode
+    jpgs = [T.synth_jpeg(w, h, seed, 85, hf, vf, rst, sg) for (w, h, hf, vf, rst, sg, seed) in specs]
+    # markers where no encoder puts them: an extra RSTn pair in the middle of an interval, a pair of fill bytes before a marker
+    extra = bytearray(jpgs[13])
+    sos = extra.index(b"\xff\xda")
+    at = sos + 14 + (len(extra) - sos) // 2
+    while extra[at - 1] == 0xFF or extra[at] == 0xFF:
+        at += 1
+    extra[at:at] = b"\xff\xd3"
+    jpgs.append(bytes(extra))
+    fill = bytearray(jpgs[14])
+    k = fill.index(b"\xff\xd0", fill.index(b"\xff\xda"))
+    fill[k:k] = b"\xff\xff"
+    jpgs.append(bytes(fill))
+    want = [T.oracle_decode(j) for j in jpgs]
+    assert sum(1 for w_ in want if w_[0] == 0 and w_[4].resyncs_dirty) >= 10 and sum(1 for w_ in want if w_[0] != 0) >= 2   # the oracle took the dirty branches
+    res = {}
+    for knob in (None, "1"):
+        if knob:
+            os.environ["HJD_NO_SEG_EMULATION"] = knob
+        try:
+            d = hjd.Decoder(0)
+            b = d.prepare(jpgs)
+            b.run()
+            b.run()   # a second run of the same batch: every per-run list is rebuilt on the device
+            st = b.finish()
+            outs = [b.download(k) if s == 0 else None for k, s in enumerate(st)]
+            res[knob] = (st, outs, b.sequential_count(), b.segment_count())
+            b.close(); d.close()
+        finally:
+            os.environ.pop("HJD_NO_SEG_EMULATION", None)
+    for knob, (st, outs, nseq, nseg) in res.items():
+        for k, (s, o, (orc, orgb, _, _, _)) in enumerate(zip(st, outs, want)):
+            if orc == 0:
+                assert s == 0 and np.array_equal(o, orgb), (knob, k, s)
+            else:
+                assert s == hjd.HJD_ERR_CORRUPT, (knob, k, s, orc)
+        assert nseq >= 12   # per finish, not per run
+        assert (nseg == 0) if knob else (nseg >= 12), (knob, nseq, nseg)
+    assert res[None][2] == res["1"][2]
+
+
 def test_mixed_restart_batch(hjd, dec):
     """Config 5 in one batch: 4:4:4 / 4:2:2 / 4:2:0, with and without DRI, different sizes."""
     specs = [(320, 240, 1, 1, 0), (320, 240, 1, 1, 10), (400, 200, 2, 1, 0), (400, 200, 2, 1, 25),
