@@ -53,10 +53,11 @@ struct HjdParams {
     const uint32_t *rst_groups; // the back-end workgroups (batch-global numbers) of those images: the grid of the gated launch
     // Segment-parallel emulation (hjd_seq.hip: k_seg_*), images of rst_list with HjdImage::seg_cap != 0:
     uint32_t nrst;             // entries of rst_list
+    uint32_t seg_cut;          // blocks after which a node's segment is cut off (at least; two restart intervals and 64 if that is more)
     uint32_t *seg_pos;         // candidates (raw byte offsets of FF xx, xx != 00), ascending per image
     uint32_t *seg_cnt;         // per entry of rst_list: candidates found; all ones = not decoded this way in this run
     uint32_t *seg_nchain;      // per entry of rst_list: nodes on the true chain
-    uint32_t *seg_plan;        // [2][nrst + 1] exclusive prefixes of the 64-node work items: segment decode, write pass
+    uint32_t *seg_plan;        // [2][nrst + 1] exclusive prefixes of the work items: segment decode, write pass
     uint32_t *seg_next;        // per node (candidate x block-in-MCU label): next candidate + 1 | label there << 25 | how the segment ended << 29
     uint4 *seg_w;              // per node: blocks, records, DC differences (Y | Cb << 16, Cr) of its segment
     uint4 *seg_base;           // per node on the chain: the same sums over everything before it

@@ -242,8 +242,9 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
 #define SEG_DEAD 4u
 #define SEG_NONE 0xFFFFFFFFu
 #define SEG_TILE 3072u // nodes of a chain tile in LDS
+#define SEG_WG 256u    // lanes (= nodes of a work item) of the two persistent kernels: four waves share the 24 KB of tables
 
-__device__ __forceinline__ uint32_t seg_cap_blocks(const HjdImage &im) { return max(256u, 2u * im.ri_blocks + 64u); }
+__device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const HjdImage &im) { return max(P.seg_cut, 2u * im.ri_blocks + 64u); }
 
 // candidates of one image, ascending; grid = the images with DRI
 __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
@@ -262,25 +263,27 @@ __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
     const uint32_t n = im.scan_len;
     uint32_t *pos = P.seg_pos + im.seg_off;
     uint32_t total = 0;
-    for (uint32_t base = 0; base < n; base += 256u * 16u) { // uniform
-        const uint32_t o = base + tid * 16u;
-        uint32_t w[5] = {0u, 0u, 0u, 0u, 0u};
-        if (o < n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(raw + o); // the slab is 16-byte aligned and padded
-            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-            if (o + 16u < n) w[4] = raw[o + 16u];
-        }
-        uint32_t mask = 0;
+    for (uint32_t base = 0; base < n; base += 256u * 64u) { // uniform; 64 bytes a lane: one block scan per 16 KB
+        const uint32_t o = base + tid * 64u;
+        uint32_t w[17];
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) {
+        for (uint32_t k = 0; k < 4u; k++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (o + k * 16u < n) v = *reinterpret_cast<const uint4 *>(raw + o + k * 16u); // the slab is 16-byte aligned and padded
+            w[k * 4u] = v.x, w[k * 4u + 1u] = v.y, w[k * 4u + 2u] = v.z, w[k * 4u + 3u] = v.w;
+        }
+        w[16] = o + 64u < n ? raw[o + 64u] : 0u;
+        uint64_t mask = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 64u; k++) {
             const uint32_t c = (w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu, d = (w[(k + 1u) >> 2] >> (((k + 1u) & 3u) * 8u)) & 0xFFu;
-            if (c == 0xFFu && d != 0u && o + k + 1u < n) mask |= 1u << k; // SeqReader::on_marker: bytes past the end read as 00
+            if (c == 0xFFu && d != 0u && o + k + 1u < n) mask |= 1ull << k; // SeqReader::on_marker: bytes past the end read as 00
         }
         uint32_t sum;
-        uint32_t at = total + block_excl_scan(__popc(mask), s_w, &sum);
+        uint32_t at = total + block_excl_scan((uint32_t)__popcll(mask), s_w, &sum);
         while (mask) {
-            const uint32_t k = __ffs(mask) - 1u;
-            mask &= mask - 1u;
+            const uint32_t k = (uint32_t)__ffsll((long long)mask) - 1u;
+            mask &= mask - 1ull;
             if (at < im.seg_cap) pos[at] = o + k;
             at++;
         }
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
     if (tid == 0) P.seg_cnt[q] = total <= im.seg_cap ? total : SEG_NONE, P.seg_nchain[q] = 0u;
 }
 
-// exclusive prefix of the images' 64-node work items: which 0 = segments (all nodes), 1 = the write pass (the chain's nodes)
+// exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's nodes)
 __global__ __launch_bounds__(256) void k_seg_plan(HjdParams P, uint32_t which)
 {
     __shared__ uint32_t s_w[17];
@@ -301,8 +304,8 @@ __global__ __launch_bounds__(256) void k_seg_plan(HjdParams P, uint32_t which)
         if (q < P.nrst) {
             if (which == 0u) {
                 const uint32_t c = P.seg_cnt[q];
-                if (c != SEG_NONE) items = ((c + 1u) * P.img[P.rst_list[q]].nb + 63u) / 64u;
-            } else items = (P.seg_nchain[q] + 63u) / 64u;
+                if (c != SEG_NONE) items = ((c + 1u) * P.img[P.rst_list[q]].nb + SEG_WG - 1u) / SEG_WG;
+            } else items = (P.seg_nchain[q] + SEG_WG - 1u) / SEG_WG;
         }
         uint32_t sum;
         const uint32_t ex = run + block_excl_scan(items, s_w, &sum);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void k_seg_plan(HjdParams P, uint32_t which)
     if (threadIdx.x == 0) plan[P.nrst] = run;
 }
 
-// work item -> (entry of rst_list, chunk of 64 nodes): the last q with plan[q] <= item
+// work item -> (entry of rst_list, chunk of SEG_WG nodes): the last q with plan[q] <= item
 __device__ __forceinline__ uint32_t seg_find(const uint32_t *plan, uint32_t nrst, uint32_t item)
 {
     uint32_t lo = 0, hi = nrst - 1u;
@@ -333,7 +336,7 @@ __device__ __forceinline__ void seg_start(SeqReader &r, const HjdParams &P, cons
 }
 
 // every node's segment, counted: a persistent grid over the work items of k_seg_plan(0) (none: every workgroup returns at once)
-__global__ __launch_bounds__(64) void k_seg_decode(HjdParams P)
+__global__ __launch_bounds__(SEG_WG) void k_seg_decode(HjdParams P)
 {
     __shared__ SeqLut s_lut[HJD_SLOTS];
     const uint32_t *plan = P.seg_plan;
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64) void k_seg_decode(HjdParams P)
             have = im.tabset;
             __syncthreads();
         }
-        const uint32_t cnt = P.seg_cnt[q], node = (item - plan[q]) * 64u + threadIdx.x;
+        const uint32_t cnt = P.seg_cnt[q], node = (item - plan[q]) * SEG_WG + threadIdx.x;
         if (node >= (cnt + 1u) * im.nb) continue;
         const uint32_t j = node / im.nb, m0 = node % im.nb;
         uint32_t kind = SEG_DEAD, nblk = 0, nrec = 0, dc[3] = {0u, 0u, 0u}, nextpos = 0;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64) void k_seg_decode(HjdParams P)
             SeqReader r;
             seg_start(r, P, im, j);
             bool check = j == 0u; // a node behind a resync starts behind the check (the reference checks once per block, :535)
-            const uint32_t cap = seg_cap_blocks(im);
+            const uint32_t cap = seg_cap_blocks(P, im);
             for (;;) {
                 if (check && r.on_marker()) {
                     kind = SEG_RESYNC;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void k_seg_chain(HjdParams P)
 }
 
 // the chain's nodes once more, writing: a persistent grid over the work items of k_seg_plan(1)
-__global__ __launch_bounds__(64) void k_seg_write(HjdParams P)
+__global__ __launch_bounds__(SEG_WG) void k_seg_write(HjdParams P)
 {
     __shared__ SeqLut s_lut[HJD_SLOTS];
     const uint32_t *plan = P.seg_plan + (P.nrst + 1u);
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64) void k_seg_write(HjdParams P)
             have = im.tabset;
             __syncthreads();
         }
-        const uint32_t k = (item - plan[q]) * 64u + threadIdx.x;
+        const uint32_t k = (item - plan[q]) * SEG_WG + threadIdx.x;
         if (k >= P.seg_nchain[q]) continue;
         const uint32_t node = P.seg_chain[im.seg_node + k];
         const uint4 base = P.seg_base[im.seg_node + node];
@@ -527,13 +530,13 @@ int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStr
 int hjd_launch_seg_emulation(const HjdParams &P, hipStream_t s)
 {
     if (!P.nrst) return 0;
-    const uint32_t grid = 4096u; // 64-lane workgroups: as many as the chip holds at once
+    const uint32_t grid = 1536u; // as many workgroups as the chip holds at once (six per CU: the tables' LDS)
     hipLaunchKernelGGL(k_seg_list, dim3(P.nrst), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 0u);
-    hipLaunchKernelGGL(k_seg_decode, dim3(grid), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(k_seg_decode, dim3(grid), dim3(SEG_WG), 0, s, P);
     hipLaunchKernelGGL(k_seg_chain, dim3(P.nrst), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 1u);
-    hipLaunchKernelGGL(k_seg_write, dim3(grid), dim3(64), 0, s, P);
+    hipLaunchKernelGGL(k_seg_write, dim3(grid), dim3(SEG_WG), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;
 }

@@ -940,6 +940,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.tk_ckpt = b->d_tkck;
     P.tk_flags = b->d_tkflags;
     P.nrst = b->seg_nnodes ? (uint32_t)b->rst_images.size() : 0u; // 0: no segment-parallel emulation in this batch
+    P.seg_cut = 256u;
+    if (const char *e = getenv("HJD_SEG_CUT")) P.seg_cut = (uint32_t)atoi(e); // tuning knob
     if (b->seg_nnodes) {
         const size_t nrst = b->rst_images.size();
         P.seg_w = reinterpret_cast<uint4 *>(b->d_seg);
