@@ -246,16 +246,56 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
 
 __device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const HjdImage &im) { return max(P.seg_cut, 2u * im.ri_blocks + 64u); }
 
+// Exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's
+// nodes).  Run by the LAST workgroup of k_seg_list / k_seg_chain to finish (a counter behind the plans; it leaves it at 0 for
+// the next run): a launch less each.  All 256 lanes of that workgroup call it; s_w: 17 words.
+__device__ __forceinline__ void seg_plan(const HjdParams &P, uint32_t which, uint32_t *s_w)
+{
+    uint32_t *plan = P.seg_plan + (size_t)which * (P.nrst + 1u);
+    uint32_t run = 0;
+    for (uint32_t q0 = 0; q0 < P.nrst; q0 += 256u) { // uniform
+        const uint32_t q = q0 + threadIdx.x;
+        uint32_t items = 0;
+        if (q < P.nrst) {
+            if (which == 0u) {
+                const uint32_t c = __hip_atomic_load(&P.seg_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c != SEG_NONE) items = ((c + 1u) * P.img[P.rst_list[q]].nb + SEG_WG - 1u) / SEG_WG;
+            } else items = (__hip_atomic_load(&P.seg_nchain[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + SEG_WG - 1u) / SEG_WG;
+        }
+        uint32_t sum;
+        const uint32_t ex = run + block_excl_scan(items, s_w, &sum);
+        if (q < P.nrst) plan[q] = ex;
+        run += sum;
+    }
+    if (threadIdx.x == 0) plan[P.nrst] = run;
+}
+
+// true in every lane of the last of the grid's workgroups to get here (everything the others wrote before is visible to it)
+__device__ __forceinline__ bool seg_last_workgroup(const HjdParams &P, uint32_t which, uint32_t *s_flag)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t *ctr = P.seg_plan + 2u * (P.nrst + 1u) + which;
+        __threadfence();
+        const uint32_t old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = old == gridDim.x - 1u ? 1u : 0u;
+        if (old == gridDim.x - 1u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return *s_flag != 0u;
+}
+
 // candidates of one image, ascending; grid = the images with DRI
 __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
 {
-    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_w[17], s_flag;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const int ii = (int)P.rst_list[q];
     const HjdImage &im = P.img[ii];
     const bool want = (P.st[ii].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) && im.seg_cap != 0u;
     if (!want) {
         if (tid == 0) P.seg_cnt[q] = SEG_NONE, P.seg_nchain[q] = 0u;
+        if (seg_last_workgroup(P, 0u, &s_flag)) seg_plan(P, 0u, s_w);
         return;
     }
     if (tid == 0) P.st[ii].emulated = 0u; // a host re-synchronisation runs this again
@@ -290,29 +330,7 @@ __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
         total += sum;
     }
     if (tid == 0) P.seg_cnt[q] = total <= im.seg_cap ? total : SEG_NONE, P.seg_nchain[q] = 0u;
-}
-
-// exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's nodes)
-__global__ __launch_bounds__(256) void k_seg_plan(HjdParams P, uint32_t which)
-{
-    __shared__ uint32_t s_w[17];
-    uint32_t *plan = P.seg_plan + (size_t)which * (P.nrst + 1u);
-    uint32_t run = 0;
-    for (uint32_t q0 = 0; q0 < P.nrst; q0 += 256u) {
-        const uint32_t q = q0 + threadIdx.x;
-        uint32_t items = 0;
-        if (q < P.nrst) {
-            if (which == 0u) {
-                const uint32_t c = P.seg_cnt[q];
-                if (c != SEG_NONE) items = ((c + 1u) * P.img[P.rst_list[q]].nb + SEG_WG - 1u) / SEG_WG;
-            } else items = (P.seg_nchain[q] + SEG_WG - 1u) / SEG_WG;
-        }
-        uint32_t sum;
-        const uint32_t ex = run + block_excl_scan(items, s_w, &sum);
-        if (q < P.nrst) plan[q] = ex;
-        run += sum;
-    }
-    if (threadIdx.x == 0) plan[P.nrst] = run;
+    if (seg_last_workgroup(P, 0u, &s_flag)) seg_plan(P, 0u, s_w);
 }
 
 // work item -> (entry of rst_list, chunk of SEG_WG nodes): the last q with plan[q] <= item
@@ -335,7 +353,7 @@ __device__ __forceinline__ void seg_start(SeqReader &r, const HjdParams &P, cons
     r.res = r.nbits = 0u;
 }
 
-// every node's segment, counted: a persistent grid over the work items of k_seg_plan(0) (none: every workgroup returns at once)
+// every node's segment, counted: a persistent grid over the work items of seg_plan(0) (none: every workgroup returns at once)
 __global__ __launch_bounds__(SEG_WG) void k_seg_decode(HjdParams P)
 {
     __shared__ SeqLut s_lut[HJD_SLOTS];
@@ -409,10 +427,13 @@ __global__ __launch_bounds__(256) void k_seg_chain(HjdParams P)
 {
     __shared__ uint32_t s_next[SEG_TILE];
     __shared__ uint4 s_wt[SEG_TILE];
-    __shared__ uint32_t s_j, s_stop;
+    __shared__ uint32_t s_j, s_stop, s_w[17], s_flag;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t cnt = P.seg_cnt[q];
-    if (cnt == SEG_NONE) return;
+    if (cnt == SEG_NONE) { // uniform
+        if (seg_last_workgroup(P, 1u, &s_flag)) seg_plan(P, 1u, s_w);
+        return;
+    }
     const int ii = (int)P.rst_list[q];
     const HjdImage &im = P.img[ii];
     const uint32_t nb = im.nb, tile = SEG_TILE / nb; // candidates per tile
@@ -464,9 +485,10 @@ __global__ __launch_bounds__(256) void k_seg_chain(HjdParams P)
             st.emulated = 2u;
         }
     }
+    if (seg_last_workgroup(P, 1u, &s_flag)) seg_plan(P, 1u, s_w);
 }
 
-// the chain's nodes once more, writing: a persistent grid over the work items of k_seg_plan(1)
+// the chain's nodes once more, writing: a persistent grid over the work items of seg_plan(1)
 __global__ __launch_bounds__(SEG_WG) void k_seg_write(HjdParams P)
 {
     __shared__ SeqLut s_lut[HJD_SLOTS];
@@ -525,17 +547,15 @@ int hjd_launch_seq_decode(const HjdParams &P, uint32_t first, uint32_t n, hipStr
     return e_ == hipSuccess ? 0 : (int)e_;
 }
 
-// The segment-parallel emulation of every flagged image of rst_list that has node space (HjdImage::seg_cap); six launches, all
-// of them gated on the device: for clean restart streams the first two return at once and the persistent grids find no work.
+// The segment-parallel emulation of every flagged image of rst_list that has node space (HjdImage::seg_cap); four launches, all
+// of them gated on the device: for clean restart streams the workgroups of the first and the third return at once and the persistent grids find no work.
 int hjd_launch_seg_emulation(const HjdParams &P, hipStream_t s)
 {
     if (!P.nrst) return 0;
     const uint32_t grid = 1536u; // as many workgroups as the chip holds at once (six per CU: the tables' LDS)
     hipLaunchKernelGGL(k_seg_list, dim3(P.nrst), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 0u);
     hipLaunchKernelGGL(k_seg_decode, dim3(grid), dim3(SEG_WG), 0, s, P);
     hipLaunchKernelGGL(k_seg_chain, dim3(P.nrst), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(k_seg_plan, dim3(1), dim3(256), 0, s, P, 1u);
     hipLaunchKernelGGL(k_seg_write, dim3(grid), dim3(SEG_WG), 0, s, P);
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : (int)e_;

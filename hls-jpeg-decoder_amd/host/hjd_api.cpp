@@ -808,7 +808,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         }
     }
     {
-        const size_t nrst = b->rst_images.size(), words = b->seg_npos + 2 * nrst + 2 * (nrst + 1) + 2 * b->seg_nnodes + 8;
+        const size_t nrst = b->rst_images.size(), words = b->seg_npos + 2 * nrst + 2 * (nrst + 1) + 2 /* the two last-workgroup counters */ + 2 * b->seg_nnodes + 8;
         if (b->seg_nnodes) need(slab_reserve(b, b->d_seg, 2 * sizeof(uint4) * b->seg_nnodes + sizeof(uint32_t) * words));
     }
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
@@ -952,6 +952,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.seg_cnt = P.seg_pos + b->seg_npos;
         P.seg_nchain = P.seg_cnt + nrst;
         P.seg_plan = P.seg_nchain + nrst;
+        HIPCHK(hipMemsetAsync(P.seg_plan + 2 * (nrst + 1), 0, 2 * sizeof(uint32_t), up)); // the counters: every run leaves them at 0
     }
     P.dbg = nullptr;
     if (getenv("HJD_SYNC_PROF")) {
