@@ -1340,10 +1340,11 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     return HJD_OK;
 }
 
-// After the run proper (everything of it is on `s` or joined to it): the sequential emulation of restart streams the parallel
-// path has just flagged DIRTY, then the back end once more for exactly those images — on the batch's side stream, which
-// waits for the run and which only hjd_batch_finish waits for.  Both launches are gated on the device: for a batch whose
-// restart streams are all clean they cost two launches of workgroups that return at once.
+// After the run proper (everything of it is on `s` or joined to it): the emulation of the reference on the restart streams the
+// parallel path has just flagged DIRTY (hjd_seq.hip: four launches parallel over the resynchronisation points, one of the
+// one-lane kernel for what those leave), then the back end once more for exactly those images — on the batch's side stream,
+// which waits for the run.  All launches are gated on the device: for a batch whose restart streams are all clean they are six
+// launches of workgroups that return at once (config 5, clean: 0.5 % of the step).
 static int emulation_enqueue(hjd_batch *b, hipStream_t s)
 {
     if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_stream) return HJD_OK;

@@ -119,10 +119,11 @@ typedef struct hjd_options {
                           * others forked from and joined to it): one range's latency-bound synchronisation then overlaps
                           * another's IDCT.  0 = by batch size (1 below 60 Mpixel, 2 up to 400, 3 above), 1 = no split */
     int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
-                          * 0 = default (8192 bits' worth), -1 = none, 1..48 = that many.  Too little warm-up is
+                          * 0 = default (16384 bits' worth, at least 4, at most 32), -1 = none, 1..48 = that many.  Too little warm-up is
                           * never wrong, only slower: hjd_batch_finish then re-synchronises from the host. */
     int dirty_mode;      /* restart streams on which the reference leaves the clean-resync domain:
-                          * 0 = decoded the way the reference decodes them, by a sequential emulation kernel (slow, exact);
+                          * 0 = decoded the way the reference decodes them, by the emulation kernels (csrc/hjd_seq.hip: exact; parallel over
+                          *     the places where the reference resynchronises, one lane per image as the fallback);
                           * 1 = refused with HJD_ERR_DIRTY_RESTART */
     int conformant;      /* SURVEY §8f N4, outside the parity contract, never the default: 1 = decode as a conforming baseline
                           * decoder would where the reference deviates — DC predictors reset at every RSTn, restart intervals

@@ -277,11 +277,11 @@ def test_dense_records_at_small_subsequences(hjd, bits):
 
 @pytest.mark.parametrize("env", [{"HJD_PHASE_WORDS": "2"}, {"HJD_PHASE_WORDS": "4", "HJD_WRITE_WINDOWS": "2"}, {"HJD_PHASE_WORDS": "8", "HJD_WRITE_WINDOWS": "8"},
                                  {"HJD_PHASE_WORDS": "32"}, {"HJD_SIBLINGS": "3"}, {"HJD_SYNC_CONC": "0", "HJD_STAGGER": "1"},
-                                 {"HJD_SYNC_OVERLAP": "0"}, {"HJD_SYNC_OVERLAP": "1"}])
+                                 {"HJD_SYNC_OVERLAP": "0"}, {"HJD_SYNC_OVERLAP": "1"}, {"HJD_NO_SEG_EMULATION": "1"}, {"HJD_SEG_CUT": "1"}])
 def test_tuning_knobs_never_change_a_byte(hjd, golden, env):
     """Window size (= checkpoint spacing = what one k_write lane decodes), windows per k_write lane, sibling trajectories forced on,
     the front-end concurrency limit, staggered ranges, in-stream repair launches, none or a single warm-up
-    subsequence per synchronisation workgroup: tuning only.  The knobs are read when a decoder is created."""
+    subsequence per synchronisation workgroup, the emulation of dirty restart streams by one lane or with its segments cut short: tuning only.  The knobs are read when a decoder is created."""
     fx = _ok_fixtures(golden, restart=("none", "clean", "dirty"))
     big = [T.synth_jpeg(1280, 720, 4242, 85, 2, 2), T.synth_jpeg(1000, 700, 4243, 90, 1, 1, 25, 9.0)]
     want = [T.oracle_decode(j)[1] for j in big]
