@@ -53,7 +53,7 @@ struct HjdParams {
     const uint32_t *rst_groups; // the back-end workgroups (batch-global numbers) of those images: the grid of the gated launch
     // Segment-parallel emulation (hjd_seq.hip: k_seg_*), images of rst_list with HjdImage::seg_cap != 0:
     uint32_t nrst;             // entries of rst_list
-    uint32_t seg_cut;          // blocks after which a node's segment is cut off (at least; two restart intervals and 64 if that is more)
+    uint32_t seg_cut;          // blocks after which a node's segment is cut off (at least two restart intervals and 64; top bit set: exactly the low bits)
     uint32_t *seg_pos;         // candidates (raw byte offsets of FF xx, xx != 00), ascending per image
     uint32_t *seg_cnt;         // per entry of rst_list: candidates found; all ones = not decoded this way in this run
     uint32_t *seg_nchain;      // per entry of rst_list: nodes on the true chain

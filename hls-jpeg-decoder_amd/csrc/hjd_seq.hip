@@ -244,7 +244,10 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
 #define SEG_TILE 3072u // nodes of a chain tile in LDS
 #define SEG_WG 256u    // lanes (= nodes of a work item) of the two persistent kernels: four waves share the 24 KB of tables
 
-__device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const HjdImage &im) { return max(P.seg_cut, 2u * im.ri_blocks + 64u); }
+__device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const HjdImage &im)
+{
+    return (P.seg_cut & 0x80000000u) ? (P.seg_cut & 0x7FFFFFFFu) : max(P.seg_cut, 2u * im.ri_blocks + 64u); // top bit: the test knob's value as it is
+}
 
 // Exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's
 // nodes).  Run by the LAST workgroup of k_seg_list / k_seg_chain to finish (a counter behind the plans; it leaves it at 0 for

@@ -941,7 +941,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.tk_flags = b->d_tkflags;
     P.nrst = b->seg_nnodes ? (uint32_t)b->rst_images.size() : 0u; // 0: no segment-parallel emulation in this batch
     P.seg_cut = 256u;
-    if (const char *e = getenv("HJD_SEG_CUT")) P.seg_cut = (uint32_t)atoi(e); // tuning knob
+    if (const char *e = getenv("HJD_SEG_CUT")) P.seg_cut = 0x80000000u | (uint32_t)(atoi(e) < 1 ? 1 : atoi(e)); // test knob: exactly this many (1: every chain meets a cut-off segment at once)
     if (b->seg_nnodes) {
         const size_t nrst = b->rst_images.size();
         P.seg_w = reinterpret_cast<uint4 *>(b->d_seg);

@@ -388,8 +388,10 @@ def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
     want = [T.oracle_decode(j) for j in jpgs]
     assert sum(1 for w_ in want if w_[0] == 0 and w_[4].resyncs_dirty) >= 10 and sum(1 for w_ in want if w_[0] != 0) >= 2   # the oracle took the dirty branches
     res = {}
-    for knob in (None, "1"):
-        if knob:
+    for knob in (None, "1", "cut"):
+        if knob == "cut":
+            os.environ["HJD_SEG_CUT"] = "2"   # every chain soon meets a cut-off segment: tried in parallel, then left to the one-lane kernel
+        elif knob:
             os.environ["HJD_NO_SEG_EMULATION"] = knob
         try:
             d = hjd.Decoder(0)
@@ -402,6 +404,7 @@ def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
             b.close(); d.close()
         finally:
             os.environ.pop("HJD_NO_SEG_EMULATION", None)
+            os.environ.pop("HJD_SEG_CUT", None)
     for knob, (st, outs, nseq, nseg) in res.items():
         for k, (s, o, (orc, orgb, _, _, _)) in enumerate(zip(st, outs, want)):
             if orc == 0:
@@ -409,8 +412,8 @@ def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
             else:
                 assert s == hjd.HJD_ERR_CORRUPT, (knob, k, s, orc)
         assert nseq >= 12   # per finish, not per run
-        assert (nseg == 0) if knob else (nseg >= 12), (knob, nseq, nseg)
-    assert res[None][2] == res["1"][2]
+        assert (nseg == 0) if knob == "1" else (nseg >= 12 if knob is None else nseg < nseq), (knob, nseq, nseg)
+    assert res[None][2] == res["1"][2] == res["cut"][2]
 
 
 def test_mixed_restart_batch(hjd, dec):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: VALU instructions of k_idct_color up to the end of phase 1 / phase 2 / whole kernel.
 # Build the variants first (here, no GPU needed):
-#   for c in 1 2; do make -s lib EXTRA=-DHJD_IDCT_CUT=$c && cp hls-jpeg-decoder_amd/lib/libhjd.so hls-jpeg-decoder_amd/lib/libhjd_cut$c.so; done; touch include/hjd.h; make -s lib
+#   for c in 1 2; do touch include/hjd.h; make -s lib EXTRA=-DHJD_IDCT_CUT=$c && cp hls-jpeg-decoder_amd/lib/libhjd.so hls-jpeg-decoder_amd/lib/libhjd_cut$c.so; done; touch include/hjd.h; make -s lib
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
