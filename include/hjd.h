@@ -145,7 +145,10 @@ hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *const *jpg, c
 void hjd_batch_destroy(hjd_batch *b);
 
 /* Enqueue the whole decode (all kernels) on `hip_stream` (a hipStream_t, may be NULL = default
- * stream).  Asynchronous; inputs and outputs stay in HBM. */
+ * stream).  Asynchronous; inputs and outputs stay in HBM.  Work the library puts on streams of its own (ranges of a split
+ * batch, small images' kernels, the emulation of dirty restart streams and the second back-end launch behind it) is joined to
+ * `hip_stream` before the call returns: whatever the caller enqueues on that stream afterwards sees the final outputs.  Statuses
+ * are final after hjd_batch_finish (which may also re-synchronise from the host; hjd_batch_resync_count). */
 int hjd_batch_run(hjd_batch *b, void *hip_stream);
 /* Wait for the stream, verify on-device convergence flags, fill status[i] (may be NULL). */
 int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status);
@@ -184,7 +187,7 @@ int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, size_t cap_wor
 /* Number of host-driven re-synchronisation rounds hjd_batch_finish had to run since prepare
  * (0 in normal operation: the warm-up subsequences of every synchronisation workgroup settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);
-/* Number of images of this batch that went through the sequential emulation of the reference (restart streams outside the
+/* Number of images of this batch that went through the emulation of the reference's sequential decoder (restart streams outside the
  * clean-resync domain) in the runs finished since prepare / reset.  The emulation is enqueued by hjd_batch_run itself, on a
  * side stream: statuses and outputs of such images are final after hjd_batch_finish. */
 int hjd_batch_sequential_count(const hjd_batch *b);
