@@ -1017,8 +1017,14 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                 // decode has wrong longest is the block's place in the MCU (it finds the code boundaries within a few hundred
                 // bits); four guesses are four draws.  (Forking the labels from the first guess's state after one staging window,
                 // of the same table class first, was the first form: one 4K image 0.240 ms of k_sync against 0.218 this way.)
+                // Siblings nb .. 2 nb - 1: the same labels, but one symbol INTO the block (z = 1: the DC symbol is behind).  On flat
+                // content under tables optimised for it (one-bit codes: every bit is a code boundary) a decode that enters at the
+                // subsequence's first bit is then always one of the 2 nb trajectories from its very start (the sweep below).
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) m[c] = sib % im.nb;
+                for (uint32_t c = 0; c < C; c++) {
+                    m[c] = sib % im.nb;
+                    z[c] = (sib / im.nb) & 1u;
+                }
             }
             decode_windows<(int)C>(E, valid, row, phs, p, z, m, nblk, nrec, mk);
             if (sib != 0u) {
@@ -1097,6 +1103,40 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     }
     stamp(4);
 
+    // Entry adoption (sibling trajectories only).  A decode that enters owned slot s exactly at its first bit, at a block's start or
+    // one symbol into it (z <= 1), with label m, IS sibling z * nb + m's decode of s from the first bit on: that sibling's checkpoints,
+    // counts and end state are the slot's, nothing is decoded.  Flat content under optimised tables (one-bit codes) enters nearly
+    // every subsequence that way, and no other trajectory ever falls into step with it there — a 4K frame of flat patches took
+    // 13-24 ms of single-lane walking.  Used whenever a refinement walk starts on a slot or moves on into the next one; and from
+    // the fourth round on a round with many items left works off only the FIRST of them (a chain round, below), so that its walk runs
+    // down the workgroup — a few loads per adopted slot, a decode where a slot is entered otherwise — instead of every slot being
+    // redone from its predecessor's stale state round after round, the truth moving on by one slot per round.  (A sweep over all
+    // slots by one lane BEFORE the rounds did the same for flat content but cost ordinary and standard-table content 0.1-0.5 ms.)
+    auto can_adopt = [&](uint32_t s, uint32_t ap, uint32_t az, uint32_t am) -> bool {
+        if (!SIBS || im.restart || s < nwarm || ap != (row0 + s) * S || az > 1u) return false;
+        const uint32_t cls = az * im.nb + am; // 0: the canonical decode's own start state
+        return cls != 0u && cls <= TK && ((tk_ok >> (cls - 1u)) & 1u);
+    };
+    auto entry_adopt = [&](uint32_t s, uint32_t &ap, uint32_t &az, uint32_t &am) -> bool {
+        if (!can_adopt(s, ap, az, am)) return false;
+        const uint32_t cls = az * im.nb + am;
+        uint2 last = make_uint2(0u, 0u);
+        uint32_t cn = 0;
+        for (uint32_t w = 0; w < nph; w++) {
+            last = *tkck(cls - 1u, w, s);
+            *ck(w, s) = last;
+            cn += ((last.y >> 9) & 2047u) | ((last.y >> 20) << 16);
+        }
+        s_up[s] = ap;
+        s_uzm[s] = (uint16_t)(az | (am << 8));
+        ap = last.x;
+        az = last.y & 63u;
+        am = (last.y >> 6) & 7u;
+        s_ep[s] = ap;
+        s_ezm[s] = (uint16_t)(az | (am << 8));
+        s_cnt[s] = cn;
+        return true;
+    };
     // Uniform regions.  Every MCU of a uniform image is the same few bits (4:2:0 with the standard tables: 32; with tables
     // optimised for the image 12 or less), so the stream is periodic, and on a periodic stream a guessed decode either falls into
     // step within a few symbols or locks into a wrong cycle for good, depending only on the bit phase it starts at (standard
@@ -1235,6 +1275,36 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             }
             __syncthreads(); // the flags have been read: s_lp is the work list again
         }
+        if (SIBS && tk_ok != 0u && !im.restart && rounds >= 3u) { // uniform
+            // A chain round?  Three rounds have not settled the workgroup, many slots are still entered in a state they were not
+            // decoded from, and most of those at their first bit in a sibling's start state: flat content (see entry_adopt).  Redoing
+            // every such slot from its predecessor's stale end moves the truth on by one slot per round.  Instead only the FIRST of
+            // them becomes an item; nothing else is marked, so its walk runs down the workgroup — a few loads per adopted slot, a
+            // decode where a slot is entered otherwise — until it reaches a slot that was decoded from the state it brings.
+            // (Every head of a stretch of such slots as an item: fewer rounds, 10-22 instead of 17-42 on the flat 4K frames, but
+            // longer ones — walks on stale states that block each other: 2.9-4.5 ms against 2.1-4.8.)
+            bool dany = false, aany = false;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                dany = dany || dirty[c];
+                aany = aany || (dirty[c] && can_adopt(sl[c], wp[c], wzm[c] & 63u, wzm[c] >> 8));
+            }
+            const uint32_t nd = (uint32_t)__syncthreads_count(dany ? 1 : 0), na = (uint32_t)__syncthreads_count(aany ? 1 : 0);
+            if (nd >= 8u && na * 2u >= nd) {
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    const unsigned long long bd = __ballot(dirty[c]);
+                    if (lane == 0) s_wc[16u + wv * C + c] = bd ? (wv * C + c) * 64u + (uint32_t)__ffsll((long long)bd) - 1u : 0xFFFFFFFFu;
+                }
+                __syncthreads();
+                uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t q = 0; q < NVW; q++) first = min(first, s_wc[16u + q]);
+                __syncthreads();
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) dirty[c] = dirty[c] && sl[c] == first;
+            }
+        }
         unsigned long long bal[C];
         bool any_moved = false;
 #pragma unroll
@@ -1280,7 +1350,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             }
             // Nobody ever walks on INTO a slot that continues a run: a walk that passes the run's first slots with a new state would go
             // on through the whole run, one lane, window after window — the run takes the new records in the next round instead.
-            if (elig[c]) s_mark[s] = (uint8_t)(rounds + 1u);
+            if (elig[c]) s_mark[s] = (uint8_t)((rounds + 1u) | 128u); // bit 7: not an item — a walk may pass through by entry adoption, never by decoding
             if (dirty[c]) {
                 const uint32_t t = base[c] + (uint32_t)__popcll(bal[c] & ((1ull << lane) - 1ull));
                 s_lp[t] = wp[c];
@@ -1319,6 +1389,37 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 #pragma unroll
             for (int c = 0; c < NC; c++) wmk[c] = live[c] ? s_mk0[slot[c]] : 0u; // the walk's marker scan: never behind the state's position, which only grows
             if (!__any(anylive)) return; // waves without work go straight to the barrier
+            // Lane c is about to decode slot[c] from (p, z, m) at window 0: while that is a sibling's start state, the slot is the
+            // sibling's (entry_adopt) and the lane moves on to the next one as a walk that reached the slot's end would.
+            // may a walk that brings (ap, az, am) enter slot nx this round?  Not an item of the round or a slot another walk has
+            // taken; a slot that continues a run only where nothing is decoded (it is a sibling's from its first bit)
+            auto may_enter = [&](uint32_t nx, uint32_t ap, uint32_t az, uint32_t am) -> bool {
+                const uint32_t mk8 = s_mark[nx];
+                if ((mk8 & 127u) != rounds + 1u) return true;
+                return (mk8 & 128u) != 0u && SIB && can_adopt(nx, ap, az, am);
+            };
+            auto move_on = [&](int c) {
+                while (live[c]) {
+                    uint32_t ap = p[c], az = z[c], am = m[c];
+                    if (!entry_adopt(slot[c], ap, az, am)) break;
+                    p[c] = ap, z[c] = az, m[c] = am;
+                    const uint32_t ezm = az | (am << 8), nx = slot[c] + 1u;
+                    live[c] = nx < NS && row0 + nx < lim && may_enter(nx, ap, az, am) && (s_up[nx] != ap || (uint32_t)s_uzm[nx] != ezm);
+                    if (live[c]) {
+                        s_mark[nx] = (uint8_t)(rounds + 1u);
+                        s_up[nx] = ap;
+                        s_uzm[nx] = (uint16_t)ezm;
+                        slot[c] = nx;
+                    }
+                }
+            };
+            if (SIB) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) move_on(c); // the items themselves
+                anylive = false;
+#pragma unroll
+                for (int c = 0; c < NC; c++) anylive = anylive || live[c];
+            }
             for (uint32_t step = 0; __any(anylive) && step < 65536u; step++) {
                 uint2 old[NC], sbl[NC][HJD_MAX_SIBLINGS];
 #pragma unroll
@@ -1372,7 +1473,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                         s_ezm[slot[c]] = (uint16_t)ezm;
                         s_cnt[slot[c]] = cn[c];
                         const uint32_t nx = slot[c] + 1u;
-                        live[c] = nx < NS && row0 + nx < lim && s_mark[nx] != rounds + 1u && (s_up[nx] != p[c] || (uint32_t)s_uzm[nx] != ezm);
+                        live[c] = nx < NS && row0 + nx < lim && may_enter(nx, p[c], z[c], m[c]) && (s_up[nx] != p[c] || (uint32_t)s_uzm[nx] != ezm);
                         if (live[c]) {
                             s_mark[nx] = (uint8_t)(rounds + 1u);
                             s_up[nx] = p[c];
@@ -1381,6 +1482,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                             ph[c] = 0u;
                             cn[c] = 0u;
                             co[c] = 0u;
+                            if (SIB) move_on(c);
                         }
                     } else if (ph[c] + 1u < nph) {
                         ph[c]++;
@@ -1389,7 +1491,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                         s_ezm[slot[c]] = (uint16_t)(z[c] | (m[c] << 8));
                         s_cnt[slot[c]] = cn[c];
                         const uint32_t nx = slot[c] + 1u;
-                        live[c] = nx < NS && row0 + nx < lim && s_mark[nx] != rounds + 1u; // walk on: nobody else works on nx this round
+                        live[c] = nx < NS && row0 + nx < lim && may_enter(nx, p[c], z[c], m[c]); // walk on: nobody else works on nx this round
                         if (live[c]) {
                             s_mark[nx] = (uint8_t)(rounds + 1u);
                             s_up[nx] = p[c];
@@ -1398,6 +1500,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                             ph[c] = 0u;
                             cn[c] = 0u;
                             co[c] = 0u;
+                            if (SIB) move_on(c);
                         }
                     }
                     anylive = anylive || live[c];

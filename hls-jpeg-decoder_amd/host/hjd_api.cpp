@@ -784,15 +784,15 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_ckpt, sizeof(uint2) * ((size_t)b->nsub * nph + (size_t)b->nsyncwg * nph * K + 1)));
     {   // Sibling trajectories (HjdParams::tk_n): when the whole batch is a few dozen synchronisation workgroups the chip sits idle
         // under k_sync's latency chain — further decodes of every subsequence cost no time then, and a refinement walk falls into
-        // step with one of up to six trajectories instead of one.  (128 workgroups in all: a launch of 16 4K images, about 90
+        // step with one of up to twelve trajectories instead of one.  (128 workgroups in all: a launch of 16 4K images, about 90
         // workgroups, gets none — the bench runs four such launches side by side, and one sibling each cost it 4 %.)
-        // HJD_SIBLINGS=0..5: tuning / test knob.
-        uint32_t tk = 0; // as many siblings (5 = every other label of a 4:2:0 MCU, 3, 2, 1) as leave the whole launch on the chip at once
-        for (uint32_t cand : {5u, 3u, 2u, 1u})
-            if (b->nsyncwg != 0 && b->nsyncwg * (cand + 1u) <= 128u) {
-                tk = cand;
-                break;
-            }
+        // HJD_SIBLINGS=0..11: tuning / test knob.
+        uint32_t tk = 0, nbmax = 3; // as many siblings (2 nb - 1 = every other label, at a block's start and one symbol into it; nb - 1 = every
+                                    // other label; 3, 2, 1) as leave the whole launch on the chip at once
+        for (auto &im : b->img) nbmax = im.nb > nbmax ? im.nb : nbmax;
+        const uint32_t limit = getenv("HJD_SIB_LIMIT") ? (uint32_t)atoi(getenv("HJD_SIB_LIMIT")) : 128u; // tuning knob
+        for (uint32_t cand : {2u * nbmax - 1u, nbmax - 1u, 3u, 2u, 1u})
+            if (tk == 0 && cand <= HJD_MAX_SIBLINGS && b->nsyncwg != 0 && b->nsyncwg * (cand + 1u) <= limit) tk = cand;
         if (const char *e = getenv("HJD_SIBLINGS")) tk = (uint32_t)(atoi(e) < 0 ? 0 : (atoi(e) > (int)HJD_MAX_SIBLINGS ? (int)HJD_MAX_SIBLINGS : atoi(e)));
         if (b->nsyncwg == 0) tk = 0;
         P.tk_n = tk;
