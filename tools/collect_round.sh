@@ -6,7 +6,7 @@ python3 tools/collect_sq.py $P/sq_counters.json 16 3840 2160 194400 $O/${T}_sq1_
 python3 tools/collect_sq.py $P/${T}_sq_counters_b32.json 32 3840 2160 194400 $O/${T}_sq1_b32 $O/${T}_sq2_b32 > /dev/null
 python3 tools/collect_traffic.py $O/${T}_fetch $O/${T}_write 16 3840 2160 $P/traffic.json > /dev/null && cp $P/traffic.json $P/${T}_traffic.json
 python3 tools/valu_mix.py $P/valu_mix.json > /dev/null
-cp $(find $O/${T}_stats -name "*kernel_stats.csv" | head -1) $P/${T}_kernel_stats.csv
+cp $(ls -t $(find $O/${T}_stats -name "*kernel_stats.csv") | head -1) $P/${T}_kernel_stats.csv   # the newest: gpurun merges every call's files into the same local directory
 grep '^{"metric"' $O/${T}_stats.log | tail -1 > $P/${T}_bench_under_rocprof.json
 tail -1 $O/${T}_bench.json > $P/${T}_bench.json
 tail -1 $O/${T}_config3_bench.json > $P/${T}_config3_bench.json
