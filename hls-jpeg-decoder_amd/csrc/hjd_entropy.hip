@@ -1772,11 +1772,16 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
         pb += t.x;
         pr += t.y;
     }
-    uint32_t base_b, base_r, tot_b, tot_r;
-    block_excl_scan(pb, s_w, &base_b);
-    block_excl_scan(pr, s_w, &base_r);
-    uint32_t blk = base_b + block_excl_scan(my_blocks, s_w, &tot_b);
-    uint32_t nrec = base_r + block_excl_scan((my_recs + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u), s_w, &tot_r);
+    // (two barriers for the four of them: four scans one after the other, three barriers each, were a good part of a lane's
+    // prologue; s_w[0..15] and s_w[16..31] are the two helpers' scratch)
+    static_assert(WGSZ <= 512, "the helpers' scratch holds eight waves");
+    uint32_t base_b = pb, base_r = pr, tot_b, tot_r;
+    block_sum2(base_b, base_r, s_w);
+    uint32_t blk = my_blocks, nrec = (my_recs + (HJD_REC_RUN - 1u)) & ~(HJD_REC_RUN - 1u);
+    block_excl_scan2(blk, nrec, s_w + 16, &tot_b, &tot_r);
+    blk += base_b;
+    nrec += base_r;
+    (void)tot_r;
     uint32_t flags = 0;
     if (tid == 0 && (wg + 1u) * WGSZ >= nsub * nu) { // the workgroup that holds the last span
         P.st[ii].total_blocks = base_b + tot_b;

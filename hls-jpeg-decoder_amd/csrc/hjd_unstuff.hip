@@ -121,8 +121,12 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(HjdParams P)
     uint4 v;
     bool listed;
     const uint32_t mm = unstuff_masks(im, P.raw, c - im.chunk0, L, &v, &listed);
-    uint32_t total; // kept bytes (<= 4096) | markers << 16 (<= 2048)
-    block_excl_scan((uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16), L.w, &total);
+    uint32_t total = (uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16); // kept bytes (<= 4096) | markers << 16 (<= 2048)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
+    if ((threadIdx.x & 63u) == 0u) L.w[threadIdx.x >> 6] = total; // (a sum, not a scan: one barrier)
+    __syncthreads();
+    total = L.w[0] + L.w[1] + L.w[2] + L.w[3];
     if (threadIdx.x == 0) {
         P.chunk_kept[c] = total & 0xFFFFu;
         P.chunk_mark[c] = total >> 16;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
 {
     __shared__ UnstuffLds L;
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 32]; // the chunk's kept bytes, MSB-first words
-    __shared__ uint32_t s_pos[UNSTUFF_T], s_mk[UNSTUFF_T];
+    __shared__ uint32_t s_pos[UNSTUFF_T], s_mk[UNSTUFF_T], s_sum[2];
     const uint32_t tid = threadIdx.x;
     const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = (int)P.map_chunk[c];
@@ -153,12 +157,23 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
         part += P.chunk_kept[im.chunk0 + k];
         mpart += P.chunk_mark[im.chunk0 + k];
     }
-    uint32_t base, mbase;
-    block_excl_scan(part, L.w, &base);
-    block_excl_scan(mpart, L.w, &mbase);
+    // their sums over the workgroup: wave sums, then two LDS atomics per wave (two block scans took six barriers for it; the
+    // first barrier inside unstuff_masks orders the atomics before the reads below)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += __shfl_xor(part, d, 64);
+        mpart += __shfl_xor(mpart, d, 64);
+    }
+    if (tid == 0) s_sum[0] = s_sum[1] = 0u;
+    __syncthreads();
+    if ((tid & 63u) == 0u) {
+        atomicAdd(&s_sum[0], part);
+        atomicAdd(&s_sum[1], mpart);
+    }
     uint4 v;
     bool listed;
     const uint32_t mm = unstuff_masks(im, P.raw, lc, L, &v, &listed);
+    const uint32_t base = s_sum[0], mbase = s_sum[1];
     uint32_t tot2;
     const uint32_t ex = block_excl_scan((uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16), L.w, &tot2);
     const uint32_t total = tot2 & 0xFFFFu, mtotal = tot2 >> 16;
@@ -272,30 +287,65 @@ __device__ __forceinline__ void dc_thread_sums(const uint2 *d, uint32_t m0, uint
     }
 }
 
+// Three sums at once over a workgroup of 256 lanes, ONE barrier each (three block_excl_scan calls were nine; these two kernels are
+// nothing but latency).  s: 12 words of LDS that nothing else touches until the next barrier.
+__device__ __forceinline__ void block_sum3(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t *s)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+        c += __shfl_xor(c, d, 64);
+    }
+    if (lane == 0) s[wv * 3u] = a, s[wv * 3u + 1u] = b, s[wv * 3u + 2u] = c;
+    __syncthreads();
+    a = s[0] + s[3] + s[6] + s[9];
+    b = s[1] + s[4] + s[7] + s[10];
+    c = s[2] + s[5] + s[8] + s[11];
+}
+
+// exclusive prefixes of three values over the workgroup's lanes, in place
+__device__ __forceinline__ void block_excl_scan3(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t *s)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b, ic = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64), tc = __shfl_up(ic, d, 64);
+        if ((int)lane >= d) ia += ta, ib += tb, ic += tc;
+    }
+    if (lane == 63u) s[wv * 3u] = ia, s[wv * 3u + 1u] = ib, s[wv * 3u + 2u] = ic;
+    __syncthreads();
+    uint32_t pa = 0, pb = 0, pc = 0;
+    for (uint32_t k = 0; k < wv; k++) pa += s[k * 3u], pb += s[k * 3u + 1u], pc += s[k * 3u + 2u];
+    a = pa + ia - a;
+    b = pb + ib - b;
+    c = pc + ic - c;
+}
+
 __global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
 {
-    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_w[12];
     const uint32_t bid = blockIdx.x + P.off_dcchunk;
     const int ii = (int)P.map_dcchunk[bid];
     const HjdImage &im = P.img[ii];
     const uint32_t nmcu = im.mcux * im.mcuy;
     const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
     const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
-    uint32_t y, cb, cr, ty, tcb, tcr;
+    uint32_t y, cb, cr;
     dc_thread_sums(P.blk + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
-    block_excl_scan(y, s_w, &ty);
-    block_excl_scan(cb, s_w, &tcb);
-    block_excl_scan(cr, s_w, &tcr);
+    block_sum3(y, cb, cr, s_w);
     if (threadIdx.x == 0) {
-        P.dcsum[bid * 3 + 0] = ty;
-        P.dcsum[bid * 3 + 1] = tcb;
-        P.dcsum[bid * 3 + 2] = tcr;
+        P.dcsum[bid * 3 + 0] = y;
+        P.dcsum[bid * 3 + 1] = cb;
+        P.dcsum[bid * 3 + 2] = cr;
     }
 }
 
 __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
 {
-    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_a[12], s_b[12];
     const uint32_t bid = blockIdx.x + P.off_dcchunk;
     const int ii = (int)P.map_dcchunk[bid];
     const HjdImage &im = P.img[ii];
@@ -303,24 +353,22 @@ __global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
     const uint32_t nmcu = im.mcux * im.mcuy;
     const uint32_t lc = bid - im.dcchunk0;
     // totals of this image's earlier chunks
-    uint32_t py = 0, pcb = 0, pcr = 0, t;
+    uint32_t by = 0, bcb = 0, bcr = 0;
     for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
-        py += P.dcsum[(im.dcchunk0 + k) * 3 + 0];
-        pcb += P.dcsum[(im.dcchunk0 + k) * 3 + 1];
-        pcr += P.dcsum[(im.dcchunk0 + k) * 3 + 2];
+        by += P.dcsum[(im.dcchunk0 + k) * 3 + 0];
+        bcb += P.dcsum[(im.dcchunk0 + k) * 3 + 1];
+        bcr += P.dcsum[(im.dcchunk0 + k) * 3 + 2];
     }
-    uint32_t by, bcb, bcr;
-    block_excl_scan(py, s_w, &by);
-    block_excl_scan(pcb, s_w, &bcb);
-    block_excl_scan(pcr, s_w, &bcr);
     const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
     const uint2 *d = P.blk + im.blk_off;
     int16_t *o = P.dca + im.blk_off;
     uint32_t y, cb, cr;
-    dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr);
-    y = by + block_excl_scan(y, s_w, &t);
-    cb = bcb + block_excl_scan(cb, s_w, &t);
-    cr = bcr + block_excl_scan(cr, s_w, &t);
+    dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr); // (its loads are in flight while the totals are added up)
+    block_sum3(by, bcb, bcr, s_a);
+    block_excl_scan3(y, cb, cr, s_b);
+    y += by;
+    cb += bcb;
+    cr += bcr;
     for (uint32_t mc = m0; mc < m1; mc++) {
         const uint2 *q = d + (size_t)mc * nb;
         int16_t *w = o + (size_t)mc * nb;
