@@ -118,10 +118,33 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_count(HjdParams P)
     const uint32_t c = blockIdx.x + P.off_chunk;
     const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
-    uint4 v;
-    bool listed;
-    const uint32_t mm = unstuff_masks(im, P.raw, c - im.chunk0, L, &v, &listed);
-    uint32_t total = (uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16); // kept bytes (<= 4096) | markers << 16 (<= 2048)
+    uint32_t total; // kept bytes (<= 4096) | markers << 16 (<= 2048)
+    if (!im.restart) {
+        // Without DRI the rule is local — a byte is dropped iff it is 00 and the byte before it is FF (an FF is never dropped
+        // itself) — so counting needs neither the list of lanes nor LDS: 0x80 per zero byte / per FF byte by the exact
+        // carry-free test, the FF flags moved on by one byte through the lane's 128 bits, AND, popcount.
+        const uint32_t lc = c - im.chunk0, tid = threadIdx.x;
+        const uint8_t *base = P.raw + im.raw_off + (size_t)lc * HJD_UNSTUFF_CHUNK + tid * 16u;
+        const uint4 q = *reinterpret_cast<const uint4 *>(base);
+        const uint32_t prevb = (lc == 0u && tid == 0u) ? 0u : base[-1];
+        const int nv = lane_nvalid(im, lc, tid);
+        auto zero80 = [](uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }; // 0x80 in every byte of x that is 0
+        const uint32_t z0 = zero80(q.x), z1 = zero80(q.y), z2 = zero80(q.z), z3 = zero80(q.w);
+        const uint32_t f0 = zero80(~q.x), f1 = zero80(~q.y), f2 = zero80(~q.z), f3 = zero80(~q.w);
+        const uint32_t fp = prevb == 0xFFu ? 0x80u : 0u;
+        // byte j of a word sits at bits 8j..8j+7: "the byte before is FF" = the FF flags shifted up by one byte, the carry coming
+        // from the word (or lane) before
+        uint32_t d0 = z0 & ((f0 << 8) | fp), d1 = z1 & ((f1 << 8) | (f0 >> 24)), d2 = z2 & ((f2 << 8) | (f1 >> 24)), d3 = z3 & ((f3 << 8) | (f2 >> 24));
+        // bytes past the end of the scan do not count
+        auto cut = [](uint32_t d, int left) { return left >= 4 ? d : (left <= 0 ? 0u : d & ((1u << (8 * left)) - 1u)); };
+        d0 = cut(d0, nv), d1 = cut(d1, nv - 4), d2 = cut(d2, nv - 8), d3 = cut(d3, nv - 12);
+        total = (uint32_t)nv - (uint32_t)(__popc(d0) + __popc(d1) + __popc(d2) + __popc(d3));
+    } else {
+        uint4 v;
+        bool listed;
+        const uint32_t mm = unstuff_masks(im, P.raw, c - im.chunk0, L, &v, &listed);
+        total = (uint32_t)__popc(mm & 0xFFFFu) | ((uint32_t)__popc(mm >> 16) << 16);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
     if ((threadIdx.x & 63u) == 0u) L.w[threadIdx.x >> 6] = total; // (a sum, not a scan: one barrier)
