@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--content", choices=("synthetic", "photo"), default="synthetic",
                     help="photo: tests/golden/Lenna.jpg (decoded by this library) mirror-tiled to the frame size, re-encoded "
                          "with per-image optimised Huffman tables — not the driver's workload, a second data point")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic images per GPU, replicated to fill its share (round 3: 8)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images per GPU, replicated to fill its share (16: profiles/r04_bench_distinct16.json)")
     ap.add_argument("--subseq-bits", type=int, default=0)
     ap.add_argument("--streams", type=int, default=4, help="split the per-GPU share over this many HIP streams")
     ap.add_argument("--internal-streams", type=int, default=0,

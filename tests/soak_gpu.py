@@ -27,6 +27,7 @@ KNOBS = [{}, {"HJD_PHASE_WORDS": "2"}, {"HJD_PHASE_WORDS": "4", "HJD_WRITE_WINDO
          {"HJD_PHASE_WORDS": "32"}, {"HJD_SYNC_OVERLAP": "0"}, {"HJD_SYNC_OVERLAP": "1"}, {"HJD_SYNC_CONC": "0", "HJD_STAGGER": "1"},
          # round 4: sibling trajectories forced on / off, the thumbnails' kernels off one by one
          {"HJD_SIBLINGS": "5"}, {"HJD_SIBLINGS": "2", "HJD_PHASE_WORDS": "8"}, {"HJD_SIBLINGS": "0"}, {"HJD_NO_SEQ_SYNC": "1"},
+         {"HJD_SIBLINGS": "11"}, {"HJD_SIBLINGS": "11", "HJD_SYNC_OVERLAP": "1"}, {"HJD_SIBLINGS": "8", "HJD_PHASE_WORDS": "4"},   # all 2 nb entering classes: entry adoption, chain rounds
          {"HJD_NO_SEQ_SYNC": "1", "HJD_NO_SMALL_SYNC": "1"},
          # dirty restart streams: the one-lane emulation instead of the segment-parallel one; segments cut off early (more fall back)
          {"HJD_NO_SEG_EMULATION": "1"}, {"HJD_SEG_CUT": "8"}]

@@ -1,0 +1,5 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; cd $R
+rm -rf $O/r04_stats; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end > $O/r04_stats.log 2>&1
+grep '^{"metric"' $O/r04_stats.log | cut -c1-200
