@@ -21,5 +21,15 @@ for n in (1, 2, 4, 8, 16):
             tot = sum(t for _, t in st)
             if best is None or tot < best[0]:
                 best = (tot, st)
-        print("n=%2d S=%4s  total %.3f ms  %s" % (n, S or "auto", best[0], " ".join("%s=%.3f" % (k, t) for k, t in best[1])), flush=True)
+        # the same run without the stage events (two events around the whole run on the default stream): what a caller sees
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        whole = None
+        for _ in range(8):
+            e0.record()
+            b.run()
+            e1.record()
+            e1.synchronize()
+            whole = e0.elapsed_time(e1) if whole is None else min(whole, e0.elapsed_time(e1))
+        b.finish()
+        print("n=%2d S=%4s  total %.3f ms  %s  | one run between two events %.3f ms" % (n, S or "auto", best[0], " ".join("%s=%.3f" % (k, t) for k, t in best[1]), whole), flush=True)
         b.close(); d.close()
