@@ -27,33 +27,32 @@ __constant__ uint8_t c_zz_to_slot_seq[64] = HJD_ZZ_TO_SLOT;
 struct SeqReader { // stHuffmanData::m_stream / stream_index / g_reservoir / g_nbits_in_reservoir (loadjpg.h:149-153)
     const uint8_t *s;
     uint32_t n, idx, res, nbits;
-    // The scan is read through a 32-byte register window (two 16-byte loads, the second fetched 16 bytes before it is needed)
-    // instead of one dependent global load per byte: the lane's chain was mostly load latency (1080p: 120 ms).
-    uint32_t b0 = 0xFFFFFFE0u; // bytes [b0, b0 + 16) in w0, [b0 + 16, b0 + 32) in w1; the scan's slab is 16-byte aligned and padded
-    uint4 w0, w1;
-    __device__ __forceinline__ uint4 load16(uint32_t base) const
+    // The scan is read through an eight-byte register window (three aligned 4-byte loads and two v_alignbyte per refill, a refill
+    // every six or seven bytes) instead of one dependent global load per byte.  (Round 3: a 32-byte window of two uint4 — the
+    // byte select through four words and the slide cost some 20 instructions per byte; the emulation kernels are instruction-bound.)
+    uint64_t w = 0;                // raw bytes [wpos, wpos + 8), byte k at bits 8k..8k+7; bytes past the end of the scan are 00
+    uint32_t wpos = 0xFFFFFFF0u;
+    __device__ __forceinline__ void refill(uint32_t pos)
     {
-        return base < n ? *reinterpret_cast<const uint4 *>(s + base) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    __device__ __forceinline__ uint32_t at(uint32_t i)
-    {
-        if (i >= n) return 0u;
-        uint32_t q = i - b0;
-        if (q >= 32u) { // first access, or a resynchronisation jumped ahead
-            b0 = i & ~15u;
-            w0 = load16(b0);
-            w1 = load16(b0 + 16u);
-            q = i - b0;
-        } else if (q >= 24u) { // slide: keeps eight bytes behind the cursor (the look-ahead is one byte)
-            b0 += 16u;
-            w0 = w1;
-            w1 = load16(b0 + 16u);
-            q -= 16u;
+        uint64_t v = 0;
+        if (pos < n) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(s + (pos & ~3u)); // the slab is 16-byte aligned and padded by 16 bytes
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], sh = pos & 3u;
+            v = ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+            const uint32_t left = n - pos;
+            if (left < 8u) v &= (1ull << (8u * left)) - 1ull;
         }
-        const uint4 w = q < 16u ? w0 : w1;
-        const uint32_t k = (q >> 2) & 3u;
-        const uint32_t word = k == 0u ? w.x : (k == 1u ? w.y : (k == 2u ? w.z : w.w));
-        return (word >> ((q & 3u) * 8u)) & 0xFFu;
+        w = v;
+        wpos = pos;
+    }
+    __device__ __forceinline__ uint32_t at(uint32_t i) // i is idx or idx + 1
+    {
+        uint32_t k = i - wpos;
+        if (k >= 8u) { // first access, the cursor has left the window, or a resynchronisation jumped ahead
+            refill(min(i, idx));
+            k = i - wpos;
+        }
+        return (uint32_t)(w >> (k * 8u)) & 0xFFu;
     }
     __device__ __forceinline__ void fill(uint32_t limit) // FillNBits, live branch loadjpg.cpp:468-482
     {
@@ -251,12 +250,12 @@ __device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const Hjd
 
 // Exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's
 // nodes).  Run by the LAST workgroup of k_seg_list / k_seg_chain to finish (a counter behind the plans; it leaves it at 0 for
-// the next run): a launch less each.  All 256 lanes of that workgroup call it; s_w: 17 words.
+// the next run): a launch less each.  All lanes of that workgroup call it; s_w: 17 words.
 __device__ __forceinline__ void seg_plan(const HjdParams &P, uint32_t which, uint32_t *s_w)
 {
     uint32_t *plan = P.seg_plan + (size_t)which * (P.nrst + 1u);
     uint32_t run = 0;
-    for (uint32_t q0 = 0; q0 < P.nrst; q0 += 256u) { // uniform
+    for (uint32_t q0 = 0; q0 < P.nrst; q0 += blockDim.x) { // uniform
         const uint32_t q = q0 + threadIdx.x;
         uint32_t items = 0;
         if (q < P.nrst) {
@@ -289,7 +288,7 @@ __device__ __forceinline__ bool seg_last_workgroup(const HjdParams &P, uint32_t 
 }
 
 // candidates of one image, ascending; grid = the images with DRI
-__global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
+__global__ __launch_bounds__(1024) void k_seg_list(HjdParams P)
 {
     __shared__ uint32_t s_w[17], s_flag;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256) void k_seg_list(HjdParams P)
     const uint32_t n = im.scan_len;
     uint32_t *pos = P.seg_pos + im.seg_off;
     uint32_t total = 0;
-    for (uint32_t base = 0; base < n; base += 256u * 64u) { // uniform; 64 bytes a lane: one block scan per 16 KB
+    for (uint32_t base = 0; base < n; base += 1024u * 64u) { // uniform; 64 bytes a lane, 1024 lanes: one block scan per 64 KB
         const uint32_t o = base + tid * 64u;
         uint32_t w[17];
 #pragma unroll
@@ -618,7 +617,7 @@ int hjd_launch_seg_emulation(const HjdParams &P, hipStream_t s)
 {
     if (!P.nrst) return 0;
     const uint32_t grid = 1536u; // as many workgroups as the chip holds at once (six per CU: the tables' LDS)
-    hipLaunchKernelGGL(k_seg_list, dim3(P.nrst), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_seg_list, dim3(P.nrst), dim3(1024), 0, s, P);
     hipLaunchKernelGGL(k_seg_decode, dim3(grid), dim3(SEG_WG), 0, s, P);
     hipLaunchKernelGGL(k_seg_chain, dim3(P.nrst), dim3(256), 0, s, P);
     hipLaunchKernelGGL(k_seg_write, dim3(grid), dim3(SEG_WG), 0, s, P);
