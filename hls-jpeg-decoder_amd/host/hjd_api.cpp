@@ -448,6 +448,16 @@ extern "C" void hjd_decoder_destroy(hjd_decoder *d)
 // ---- batch --------------------------------------------------------------------------------------
 
 // (Re)allocates *p when it holds less than `bytes`; keeps it otherwise.
+// Bytes of the one slab behind the segment-parallel emulation (hjd_seq.hip), carved up in batch_build: per node two uint4 (segment
+// sums, sums before it) and two words (successor, place on the chain); per candidate a position; per image with DRI a candidate
+// count and a chain length; two work-item prefixes over those images; the two last-workgroup counters.
+static size_t seg_slab_size(const hjd_batch *b)
+{
+    if (!b->seg_nnodes) return 0;
+    const size_t nrst = b->rst_images.size(), words = b->seg_npos + 2 * nrst + 2 * (nrst + 1) + 2 + 2 * b->seg_nnodes + 8;
+    return 2 * sizeof(uint4) * b->seg_nnodes + sizeof(uint32_t) * words;
+}
+
 template <class T>
 static int slab_reserve(hjd_batch *b, T *&p, size_t bytes)
 {
@@ -807,10 +817,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             }
         }
     }
-    {
-        const size_t nrst = b->rst_images.size(), words = b->seg_npos + 2 * nrst + 2 * (nrst + 1) + 2 /* the two last-workgroup counters */ + 2 * b->seg_nnodes + 8;
-        if (b->seg_nnodes) need(slab_reserve(b, b->d_seg, 2 * sizeof(uint4) * b->seg_nnodes + sizeof(uint32_t) * words));
-    }
+    if (b->seg_nnodes) need(slab_reserve(b, b->d_seg, seg_slab_size(b)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint2) * (blk_cur + 1)));
@@ -1187,6 +1194,9 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
         const size_t nph = (b.P.subseq_bits / 32) / b.P.phase_words;
         o->ckpt_entries = (size_t)b.nsub * nph + (size_t)b.nsyncwg * nph * b.P.sync_overlap + 1;
     }
+    o->seg_cap = im.seg_cap;
+    o->seg_nodes = b.seg_nnodes;
+    o->seg_slab_bytes = seg_slab_size(&b);
     o->lds_bytes_sync = b.P.lds_bytes_sync;
     o->lds_bytes_write = b.P.lds_bytes_write;
     o->lds_state_word = b.P.lds_state_word;

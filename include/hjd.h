@@ -236,6 +236,9 @@ typedef struct hjd_layout_info {
     uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word, lds_state_word_sync;
     uint64_t raw_bytes, ustream_bytes, blk_entries, dca_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
         dcsum_entries, ckpt_entries;
+    /* segment-parallel emulation of dirty restart streams (csrc/hjd_seq.hip; all 0 without DRI): candidates reserved, nodes
+     * (= (seg_cap + 1) * nb), bytes of the slab that holds the candidate list, the per-node arrays, counters and plans */
+    uint64_t seg_cap, seg_nodes, seg_slab_bytes;
 } hjd_layout_info;
 int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int sync_overlap, int out_format, hjd_layout_info *out);
 

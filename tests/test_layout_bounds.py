@@ -114,3 +114,14 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         # --- restart markers: one entry per marker a well-formed scan holds, and the kernels clamp to mark_cap
         if rst:
             assert o.mark_cap >= -(-mcus // rst) - 1
+            # --- segment-parallel emulation (hjd_seq.hip): k_seg_list writes pos[at] only for at < seg_cap and gives the image up
+            #     beyond; nodes j * nb + m, j <= candidates <= seg_cap; per node 2 x 16 + 2 x 4 bytes, per candidate 4, per image
+            #     with DRI (one here) a count, a chain length and two plan entries, one more plan entry each, two counters
+            n_rst = -(-mcus // rst) - 1
+            assert o.seg_cap >= n_rst + 1 and o.seg_cap + 1 < (1 << 25)           # the successor field holds candidate + 1 in 25 bits
+            assert o.seg_nodes == (o.seg_cap + 1) * o.nb
+            assert o.seg_slab_bytes >= 40 * o.seg_nodes + 4 * (o.seg_cap + 2 + 2 * 2 + 2)
+            tile = 512 if o.nb <= 6 else 256                                       # k_seg_chain: candidates per LDS tile
+            assert tile * o.nb <= 3072 and tile <= 512                            # s_lnk[9][3072], s_d[512]
+        else:
+            assert o.seg_cap == 0 and o.seg_nodes == 0 and o.seg_slab_bytes == 0
