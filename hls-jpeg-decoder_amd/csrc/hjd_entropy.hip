@@ -346,18 +346,18 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         // DC symbol (loadjpg.cpp:562-667): the block's entry begins here
         W.bfirst = isdc ? nrec : W.bfirst;
         W.bdc = isdc ? (uint32_t)(int)(int16_t)val : W.bdc;
-        W.tag = isdc ? (nblk & 127u) << 22 : W.tag;
+        // (W.tag = the block bits of the block in progress: set by the caller and at every block's end — computing it here on every
+        // DC symbol was three instructions in every iteration)
         // the reference looks for a marker again between the DC code and its extra bits
         if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
         const uint32_t zw = z + adv - 1u;
         if (!isdc && s != 0u) { // AC run/size: loadjpg.cpp:776-808
             const uint32_t slot = W.slot_of[zw & 63u];
-            uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag;
-            if (zw > 63u) { // the reference writes DCT[nr] out of bounds here (:780-806): flagged, never a record (a rare branch:
-                            // no lane of a wave takes it on a stream the reference can decode)
-                flags |= HJD_FLAG_OVERRUN;
-                w = HJD_REC_PAD;
-            }
+            const uint32_t w = ((uint32_t)val & 0xFFFFu) | (slot << 16) | W.tag;
+            // zw > 63: the reference writes DCT[nr] out of bounds here (:780-806): flagged — zw <= 63 + 15, so bit 6 says it; the
+            // record (of slot zw & 63) stays where it is: the image's output is not looked at
+            static_assert(HJD_FLAG_OVERRUN == 2u, "bit 6 of zw moved to bit 1");
+            flags |= (zw >> 5) & HJD_FLAG_OVERRUN;
             static_assert(HJD_REC_RUN % 4 == 0 && (HJD_REC_RUN & (HJD_REC_RUN - 1)) == 0, "16-byte pieces");
             W.ring[(nrec & (HJD_REC_RUN - 1u)) * WGSZ] = w;
             if ((nrec & (HJD_REC_RUN - 1u)) == HJD_REC_RUN - 1u) { // a burst is complete: whole, aligned sectors
@@ -383,6 +383,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             z = 0u;
             write_block_entry<ENTCAP>(W, nblk);
             nblk++;
+            W.tag = (nblk & 127u) << 22;
             if (nblk == W.nblocks) {
                 W.blk[nblk] = make_uint2(nrec, 0u); // end of the last block's records
                 end = p;                                    // the image is complete: what follows is not looked at
