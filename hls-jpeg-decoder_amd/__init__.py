@@ -23,9 +23,9 @@ MAX_STAGES = 16
 EXPORTS = [
     "hjd_status_string", "hjd_last_status", "hjd_convert_jpg_file", "hjd_decode_jpg_file_data", "hjd_free",
     "hjd_parse_header", "hjd_parse_header_ex", "hjd_jpeg_decode_hw", "hjd_decoder_create", "hjd_decoder_destroy", "hjd_device_count",
-    "hjd_batch_prepare", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
+    "hjd_batch_prepare", "hjd_batch_prepare_parsed", "hjd_batch_destroy", "hjd_batch_run", "hjd_batch_finish", "hjd_batch_image_info",
     "hjd_batch_out_device_ptr", "hjd_batch_out_bytes", "hjd_batch_download", "hjd_batch_totals",
-    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_sequential_count", "hjd_batch_segment_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query", "hjd_debug_sync_profile",
+    "hjd_batch_run_timed", "hjd_batch_sync_stats", "hjd_batch_resync_count", "hjd_batch_path_counts", "hjd_batch_sequential_count", "hjd_batch_segment_count", "hjd_batch_enable_timing", "hjd_batch_collect_timing", "hjd_decode_batch_host", "hjd_bmp_bytes", "hjd_rgb_bytes", "hjd_batch_download_coefs", "hjd_test_color_table", "hjd_batch_create", "hjd_batch_reset", "hjd_host_alloc", "hjd_host_free", "hjd_layout_query", "hjd_debug_sync_profile",
 ]
 
 
@@ -53,7 +53,19 @@ class LayoutInfo(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("subseq_bits", ctypes.c_int), ("sync_launches", ctypes.c_int), ("streams", ctypes.c_int),
-                ("sync_overlap", ctypes.c_int), ("dirty_mode", ctypes.c_int), ("conformant", ctypes.c_int), ("reserved", ctypes.c_int * 2)]
+                ("sync_overlap", ctypes.c_int), ("dirty_mode", ctypes.c_int), ("conformant", ctypes.c_int), ("debug_flags", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+# hjd_options.debug_flags (include/hjd.h: HJD_DBG_*)
+DBG_NO_SMALL_SYNC, DBG_NO_SEQ_SYNC, DBG_NO_SEG_EMULATION = 1, 2, 4
+
+
+def dbg_siblings(n):
+    return ((n + 1) & 15) << 8
+
+
+def dbg_seg_cut(n):
+    return (n & 0x7FFF) << 16
 
 
 _lib = None
@@ -99,6 +111,8 @@ def lib():
     L.hjd_batch_prepare.restype = vp
     L.hjd_batch_prepare.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz),
                                     ctypes.c_int, ip]
+    L.hjd_batch_prepare_parsed.restype = vp
+    L.hjd_batch_prepare_parsed.argtypes = [vp, ctypes.c_int, ctypes.POINTER(JpegData), ctypes.c_int, ip]
     L.hjd_batch_destroy.restype = None
     L.hjd_batch_destroy.argtypes = [vp]
     L.hjd_batch_run.restype = ctypes.c_int
@@ -129,6 +143,8 @@ def lib():
                                            ctypes.c_int, ip]
     L.hjd_batch_sync_stats.restype = ctypes.c_int
     L.hjd_batch_sync_stats.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    L.hjd_batch_path_counts.restype = ctypes.c_int
+    L.hjd_batch_path_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.hjd_batch_resync_count.restype = ctypes.c_int
     L.hjd_batch_resync_count.argtypes = [vp]
     L.hjd_batch_sequential_count.restype = ctypes.c_int
@@ -171,8 +187,8 @@ def parse_header(jpg):
 class Decoder:
     """hjd_decoder: one per (process, device)."""
 
-    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0, dirty_mode=0, conformant=0):
-        opt = Options(subseq_bits, sync_launches, streams, sync_overlap, dirty_mode, conformant)
+    def __init__(self, device=0, subseq_bits=0, sync_launches=0, streams=0, sync_overlap=0, dirty_mode=0, conformant=0, debug_flags=0):
+        opt = Options(subseq_bits, sync_launches, streams, sync_overlap, dirty_mode, conformant, debug_flags, 0)
         self._h = lib().hjd_decoder_create(device, ctypes.byref(opt))
         if not self._h:
             raise RuntimeError("hjd_decoder_create failed: %s" % status_string(lib().hjd_last_status()))
@@ -198,6 +214,10 @@ class Decoder:
 
     def prepare(self, jpgs, out_format=OUT_RGB):
         return Batch(self, jpgs, out_format)
+
+    def prepare_parsed(self, jdatas, keep_alive=(), out_format=OUT_RGB):
+        """hjd_batch_prepare_parsed: JpegData structs the caller filled (their stream pointers must stay valid: keep_alive)."""
+        return Batch(self, keep_alive, out_format, parsed=list(jdatas))
 
     def decode_host(self, jpgs, out_format=OUT_RGB, pinned=True, outputs=None):
         """hjd_decode_batch_host: host JPEG bytes -> host RGB/BMP bytes through the three-stream pipeline.
@@ -268,15 +288,21 @@ class PinnedArray(np.ndarray):
 
 
 class Batch:
-    def __init__(self, dec, jpgs, out_format):
+    def __init__(self, dec, jpgs, out_format, parsed=None):
         self._dec = dec
         self._jpgs = list(jpgs)  # keep alive while preparing
-        self.n = len(self._jpgs)
         self.out_format = out_format
-        arr = (ctypes.c_char_p * self.n)(*self._jpgs)
-        lens = (ctypes.c_size_t * self.n)(*[len(j) for j in self._jpgs])
-        st = (ctypes.c_int * self.n)()
-        self._h = lib().hjd_batch_prepare(dec._h, self.n, arr, lens, out_format, st)
+        if parsed is not None:
+            self.n = len(parsed)
+            arr = (JpegData * self.n)(*parsed)
+            st = (ctypes.c_int * self.n)()
+            self._h = lib().hjd_batch_prepare_parsed(dec._h, self.n, arr, out_format, st)
+        else:
+            self.n = len(self._jpgs)
+            arr = (ctypes.c_char_p * self.n)(*self._jpgs)
+            lens = (ctypes.c_size_t * self.n)(*[len(j) for j in self._jpgs])
+            st = (ctypes.c_int * self.n)()
+            self._h = lib().hjd_batch_prepare(dec._h, self.n, arr, lens, out_format, st)
         if not self._h:
             raise RuntimeError("hjd_batch_prepare failed: %s" % status_string(lib().hjd_last_status()))
         self.parse_status = list(st)
@@ -331,6 +357,11 @@ class Batch:
         a = (ctypes.c_uint32 * 4)()
         lib().hjd_batch_sync_stats(self._h, i, a)
         return dict(iters=a[0], decodes=a[1], iters_max=a[2], nsub=a[3])
+
+    def path_counts(self):
+        a = (ctypes.c_uint32 * 4)()
+        lib().hjd_batch_path_counts(self._h, a)
+        return dict(sync_seq=a[0], sync_small=a[1], sync_large=a[2], write_small=a[3])
 
     def resync_count(self):
         return lib().hjd_batch_resync_count(self._h)

@@ -113,10 +113,12 @@ struct HjdImage {
     uint32_t out_stride;    // bytes per output row (3W, or BMP padded)
     uint32_t out_format;    // 0 RGB, 1 BMP
     uint32_t restart;       // DRI seen: the reference's resync checks are live (loadjpg.cpp:535-550, :631-640)
-    uint32_t ri_blocks;     // blocks per restart interval (Ri * nb); 0 when Ri = 0
+    uint32_t ri_blocks;     // blocks per restart interval (Ri * nb); 0 = not known (the reference's own host never passes Ri on,
+                            // openjpg.cpp:441-446, and neither does a DRI segment that says 0): markers are taken where they are
     uint32_t mark_off;      // first entry of this image in the marker arrays
     uint32_t mark_cap;      // entries reserved
-    uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1
+    uint32_t n_rst;         // RSTn markers a well-formed scan of this size holds: ceil(nmcu/Ri) - 1 (Ri not known: the pairs the
+                            // host counted in the scan before EOI)
     uint32_t rec_cap;       // records reserved
     uint32_t conformant;    // hjd_options.conformant: DC reset at RSTn, true-cosine rounding IDCT, rounding colour
     uint32_t sync_small;    // 1: the image's one synchronisation workgroup is a small one (k_sync_small, its own numbering);
@@ -126,7 +128,8 @@ struct HjdImage {
     uint32_t seg_cap;       // segment-parallel emulation (hjd_seq.hip): candidates reserved (0: none — the image is left to k_seq_decode),
     uint32_t seg_off;       //   first entry in seg_pos,
     uint32_t seg_node;      //   first node ((seg_cap + 1) * nb nodes) in seg_next / seg_w / seg_base / seg_chain
-    uint32_t seg_pad_;
+    uint32_t seg_ri;        //   blocks per restart interval for the cut-off length of a segment: ri_blocks, or (Ri not known) the
+                            //   image's blocks over the marker pairs the host counted
     uint64_t raw_off;       // byte offset into raw slab
     uint64_t ustream_off;   // byte offset into ustream slab (multiple of 16)
     uint64_t blk_off;       // first entry of this image in blk (nblocks + 1 entries per image)

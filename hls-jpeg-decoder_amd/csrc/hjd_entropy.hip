@@ -419,8 +419,11 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             if (blk_end) rc.left--;
             if ((blk_end && p + 8u > mnext) || p > mnext) {
                 if (nblk < W.nblocks) {
-                    // clean only if a whole interval of whole MCUs ends exactly here
-                    const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u ? false : rc.left == 0u);
+                    // clean only if a whole interval of whole MCUs ends exactly here.  ri_blocks = 0: the interval is not known
+                    // (HjdImage::ri_blocks) — the reference's check fires at this block start whatever the count
+                    // (loadjpg.cpp:535-550 tests the two bytes under its cursor and nothing else) and, the MCU being complete,
+                    // goes on exactly as this loop does: marker skipped, reservoir dropped, first block of an MCU next
+                    const bool clean = blk_end && p <= mnext && m == 0u && (rc.ri_blocks == 0u || rc.left == 0u);
                     if (!clean) flags |= HJD_FLAG_DIRTY;
                 }
                 p = mnext;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
 
 __device__ __forceinline__ uint32_t seg_cap_blocks(const HjdParams &P, const HjdImage &im)
 {
-    return (P.seg_cut & 0x80000000u) ? (P.seg_cut & 0x7FFFFFFFu) : max(P.seg_cut, 2u * im.ri_blocks + 64u); // top bit: the test knob's value as it is
+    return (P.seg_cut & 0x80000000u) ? (P.seg_cut & 0x7FFFFFFFu) : max(P.seg_cut, 2u * im.seg_ri + 64u); // top bit: the test knob's value as it is
 }
 
 // Exclusive prefix of the images' work items (SEG_WG nodes each): which 0 = segments (all nodes), 1 = the write pass (the chain's

@@ -127,7 +127,7 @@ struct hjd_decoder {
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
     uint32_t phase_words = 16; // words of a subsequence staged in LDS at a time = the window one k_write lane decodes
     int streams = 0;           // image ranges a batch is split into (hjd_options.streams); 0 = by batch size
-    // Front-end concurrency limit (HJD_SYNC_CONC / hjd_options.reserved[0]): the synchronisation kernel is a latency chain that
+    // Front-end concurrency limit (HJD_SYNC_CONC): the synchronisation kernel is a latency chain that
     // fills a fraction of the chip's issue slots; batches run on several caller streams otherwise march in lock step (all in
     // their synchronisation at once, then all in their IDCT).  With a limit G the k-th run's synchronisation waits for that of
     // run k-G: the runs spread out in time, so that at any moment some are in the latency-bound stage and the others in the
@@ -140,6 +140,15 @@ struct hjd_decoder {
     int stagger = 0;           // ranges of a batch run as a software pipeline (batch_enqueue): 0 off, 1 after sync, 2 after the final pass
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
     int conformant = 0;        // hjd_options.conformant: opt-in, outside the parity contract
+    // hjd_options.debug_flags (test switches: they select among paths that must all give the same bytes) and the diagnostics /
+    // tuning variables of the environment — all read ONCE, here, when the decoder is created: a batch never looks at the
+    // environment (round 4 called getenv per image and per prepare, on caller threads)
+    bool no_small_sync = false, no_seq_sync = false, no_seg_emulation = false;
+    int siblings = -1;         // -1 = by launch size, 0..HJD_MAX_SIBLINGS = exactly that many
+    uint32_t sib_limit = 128;  // HJD_SIB_LIMIT: workgroups (with siblings) a launch may have and still get siblings
+    uint32_t seg_cut = 0;      // 0 = default (256 blocks or two restart intervals + 64), else exactly that many
+    bool sync_prof = false, verbose = false;
+    int max_resync = 4096;
     // host-to-host pipeline (hjd_decode_batch_host): a ring of re-usable batches and three streams, so that chunk
     // k+1's upload and chunk k-1's download run beside chunk k's kernels
     struct Slot {
@@ -388,7 +397,17 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         if (opt->streams > 0) d->streams = opt->streams > 16 ? 16 : opt->streams;
         d->dirty_mode = opt->dirty_mode ? 1 : 0;
         d->conformant = opt->conformant ? 1 : 0;
+        const unsigned f = (unsigned)opt->debug_flags;
+        d->no_small_sync = (f & HJD_DBG_NO_SMALL_SYNC) != 0;
+        d->no_seq_sync = (f & HJD_DBG_NO_SEQ_SYNC) != 0;
+        d->no_seg_emulation = (f & HJD_DBG_NO_SEG_EMULATION) != 0;
+        if ((f >> 8) & 15u) d->siblings = (int)((f >> 8) & 15u) - 1 > (int)HJD_MAX_SIBLINGS ? (int)HJD_MAX_SIBLINGS : (int)((f >> 8) & 15u) - 1;
+        d->seg_cut = (f >> 16) & 0x7FFFu;
     }
+    if (const char *e = getenv("HJD_SIB_LIMIT")) d->sib_limit = (uint32_t)(atoi(e) < 0 ? 0 : atoi(e)); // tuning knob
+    d->sync_prof = getenv("HJD_SYNC_PROF") != nullptr;  // diagnostics
+    d->verbose = getenv("HJD_VERBOSE") != nullptr;
+    if (const char *e = getenv("HJD_MAX_RESYNC")) d->max_resync = atoi(e);
     if (const char *ew = getenv("HJD_WRITE_WINDOWS"))
         if (atoi(ew) >= 1 && atoi(ew) <= 64 && (atoi(ew) & (atoi(ew) - 1)) == 0) d->write_windows = (uint32_t)atoi(ew);
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
@@ -625,9 +644,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->nsub += im.nsub_cap;
         // An image whose whole scan fits one small synchronisation workgroup (with the same warm-up allowance) gets one:
         // k_sync_small, numbered on its own
-        im.sync_small = (K < HJD_SYNC_WG_SMALL && im.nsub_cap <= HJD_SYNC_WG_SMALL - K && !getenv("HJD_NO_SMALL_SYNC")) ? 1u : 0u;
+        im.sync_small = (K < HJD_SYNC_WG_SMALL && im.nsub_cap <= HJD_SYNC_WG_SMALL - K && !d->no_small_sync) ? 1u : 0u;
         // ... and a thumbnail (no restart markers, a scan of at most HJD_SEQ_MAX_BITS) none at all: one lane of k_sync_seq decodes it
-        if (im.sync_small && j.restart_interval <= 0 && (uint64_t)im.scan_len * 8u <= HJD_SEQ_MAX_BITS && !getenv("HJD_NO_SEQ_SYNC")) im.sync_small = 2u;
+        if (im.sync_small && j.restart_interval <= 0 && (uint64_t)im.scan_len * 8u <= HJD_SEQ_MAX_BITS && !d->no_seq_sync) im.sync_small = 2u;
         if (im.sync_small == 2u) {
             im.syncwg0 = 0;
             im.nsyncwg = 0;
@@ -668,9 +687,31 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.conformant = d->conformant ? 1u : 0u;
         im.ri_blocks = im.restart ? j.restart_mcus * im.nb : 0u;
         im.mark_off = b->nmarks;
-        im.mark_cap = im.restart ? (j.restart_mcus ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus : 0u) + 8u : 0u;
+        if (im.restart && j.restart_mcus == 0) {
+            // The interval is not known: what an unmodified reference host hands over at the HW/SW cut (openjpg.cpp:441-446 keeps
+            // the DRI segment's LENGTH, never Ri), or a DRI segment that says 0.  The reference itself never knows it either — it
+            // resynchronises wherever its byte cursor meets FF xx at a block start (loadjpg.cpp:535-550) — so the markers are taken
+            // where the scan holds them: counted here by the unstuff stage's own pair rule (keepmask_rule, restart form), which
+            // sizes the marker and candidate slabs; ri_blocks = 0 tells the final pass that no block count goes with a marker.
+            uint32_t pairs = 0, before_eoi = 0xFFFFFFFFu;
+            unsigned prev = 0;
+            if (b->dry) pairs = (uint32_t)(j.stream_len / 2); // hjd_layout_query never reads the scan: the bound instead of the count
+            for (size_t q = 0; q < j.stream_len && !b->dry; q++) {
+                const unsigned bv = j.stream[q];
+                const bool second = prev == 0xFFu;
+                if (second && bv != 0) {
+                    if (bv == 0xD9 && before_eoi == 0xFFFFFFFFu) before_eoi = pairs;
+                    pairs++;
+                }
+                prev = second ? 0u : bv;
+            }
+            im.mark_cap = pairs + 8u;
+            im.n_rst = before_eoi == 0xFFFFFFFFu ? pairs : before_eoi; // everything before EOI has to be an RSTn (k_unstuff_write)
+        } else {
+            im.mark_cap = im.restart ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus + 8u : 0u;
+            im.n_rst = im.restart ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus - 1 : 0u;
+        }
         b->nmarks += im.mark_cap;
-        im.n_rst = (im.restart && j.restart_mcus) ? (im.mcux * im.mcuy + j.restart_mcus - 1) / j.restart_mcus - 1 : 0u;
         size_t obytes;
         if (b->out_format == HJD_OUT_BMP) {
             im.out_stride = (im.width * 3 + 3) & ~3u;
@@ -722,15 +763,19 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     for (int k = 0; k < b->nimg; k++)
         if (b->img[k].restart) b->rst_images.push_back((uint32_t)k);
     {   // Node space of the segment-parallel emulation (hjd_seq.hip: candidates x block-in-MCU labels, 40 bytes a node), in image
-        // order until the budget is spent; an image without any is left to the one-lane kernel.  HJD_NO_SEG_EMULATION=1: test knob.
+        // order until the budget is spent; an image without any is left to the one-lane kernel.  hjd_options.debug_flags HJD_DBG_NO_SEG_EMULATION: test switch.
+        // The budget is counted in NODES and capped in bytes: 2 M nodes x 40 B = 80 MB per batch at most (round 4 reserved up to
+        // 16 M nodes = 640 MB, up front, for every image with DRI whether or not it is ever flagged dirty); images beyond it fall
+        // back to the one-lane kernel.
         size_t pos_cur = 0, node_cur = 0;
-        const size_t budget = (size_t)16 << 20;
-        const bool off = getenv("HJD_NO_SEG_EMULATION") != nullptr || d->dirty_mode != 0;
+        const size_t budget = ((size_t)80 << 20) / 40;
+        const bool off = d->no_seg_emulation || d->dirty_mode != 0;
         for (uint32_t q : b->rst_images) {
             HjdImage &im = b->img[q];
             const uint32_t cap = im.mark_cap + im.n_rst / 8u; // a well-formed scan holds n_rst of them
             const size_t nodes = (size_t)(cap + 1u) * im.nb;
-            im.seg_cap = im.seg_off = im.seg_node = im.seg_pad_ = 0u;
+            im.seg_cap = im.seg_off = im.seg_node = 0u;
+            im.seg_ri = im.ri_blocks ? im.ri_blocks : (im.nblocks + im.n_rst) / (im.n_rst + 1u);
             if (off || node_cur + nodes > budget || cap >= (1u << 24)) continue;
             im.seg_cap = cap;
             im.seg_off = (uint32_t)pos_cur;
@@ -796,14 +841,14 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // under k_sync's latency chain — further decodes of every subsequence cost no time then, and a refinement walk falls into
         // step with one of up to twelve trajectories instead of one.  (128 workgroups in all: a launch of 16 4K images, about 90
         // workgroups, gets none — the bench runs four such launches side by side, and one sibling each cost it 4 %.)
-        // HJD_SIBLINGS=0..11: tuning / test knob.
+        // hjd_options.debug_flags (HJD_DBG_SIBLINGS): tuning / test switch.
         uint32_t tk = 0, nbmax = 3; // as many siblings (2 nb - 1 = every other label, at a block's start and one symbol into it; nb - 1 = every
                                     // other label; 3, 2, 1) as leave the whole launch on the chip at once
         for (auto &im : b->img) nbmax = im.nb > nbmax ? im.nb : nbmax;
-        const uint32_t limit = getenv("HJD_SIB_LIMIT") ? (uint32_t)atoi(getenv("HJD_SIB_LIMIT")) : 128u; // tuning knob
+        const uint32_t limit = d->sib_limit;
         for (uint32_t cand : {2u * nbmax - 1u, nbmax - 1u, 3u, 2u, 1u})
             if (tk == 0 && cand <= HJD_MAX_SIBLINGS && b->nsyncwg != 0 && b->nsyncwg * (cand + 1u) <= limit) tk = cand;
-        if (const char *e = getenv("HJD_SIBLINGS")) tk = (uint32_t)(atoi(e) < 0 ? 0 : (atoi(e) > (int)HJD_MAX_SIBLINGS ? (int)HJD_MAX_SIBLINGS : atoi(e)));
+        if (d->siblings >= 0) tk = (uint32_t)d->siblings; // hjd_options.debug_flags: exactly that many
         if (b->nsyncwg == 0) tk = 0;
         P.tk_n = tk;
         P.tk_stride = (uint64_t)b->nsub * nph;
@@ -948,7 +993,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.tk_flags = b->d_tkflags;
     P.nrst = b->seg_nnodes ? (uint32_t)b->rst_images.size() : 0u; // 0: no segment-parallel emulation in this batch
     P.seg_cut = 256u;
-    if (const char *e = getenv("HJD_SEG_CUT")) P.seg_cut = 0x80000000u | (uint32_t)(atoi(e) < 1 ? 1 : atoi(e)); // test knob: exactly this many (1: every chain meets a cut-off segment at once)
+    if (d->seg_cut) P.seg_cut = 0x80000000u | d->seg_cut; // test switch: exactly this many (1: every chain meets a cut-off segment at once)
     if (b->seg_nnodes) {
         const size_t nrst = b->rst_images.size();
         P.seg_w = reinterpret_cast<uint4 *>(b->d_seg);
@@ -962,7 +1007,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         HIPCHK(hipMemsetAsync(P.seg_plan + 2 * (nrst + 1), 0, 2 * sizeof(uint32_t), up)); // the counters: every run leaves them at 0
     }
     P.dbg = nullptr;
-    if (getenv("HJD_SYNC_PROF")) {
+    if (d->sync_prof) {
         need(slab_reserve(b, b->d_dbg, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1)));
         if (rcs != HJD_OK) return rcs;
         HIPCHK(hipMemsetAsync(b->d_dbg, 0, sizeof(unsigned long long) * 32 * (b->nsyncwg + 1), up));
@@ -1250,6 +1295,21 @@ extern "C" hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *co
     return batch_from_parsed(d, n, parsed, pst, out_format, status);
 }
 
+// The batch-level twin of hjd_jpeg_decode_hw: N images whose headers the CALLER has parsed (the reference's own JpegParseHeader
+// through include/hjd_reference_shim.h, say).  Every struct gets the checks hjd_parse_header applies (batch_build).
+extern "C" hjd_batch *hjd_batch_prepare_parsed(hjd_decoder *d, int n, const hjd_jpeg_data *jdata, int out_format, int *status)
+{
+    if (!d || n < 0 || (n && !jdata) || (out_format != HJD_OUT_RGB && out_format != HJD_OUT_BMP)) {
+        hjd_set_last_status(HJD_ERR_ARG);
+        return nullptr;
+    }
+    std::vector<hjd_jpeg_data> parsed(jdata, jdata + n);
+    std::vector<int> pst(n, HJD_OK);
+    for (int i = 0; i < n; i++)
+        if (!parsed[i].stream) pst[i] = HJD_ERR_ARG;
+    return batch_from_parsed(d, n, parsed, pst, out_format, status);
+}
+
 // the kernel sequence; ev != nullptr records an event before each stage and one after the last
 // the kernel sequence for one range of images; names != nullptr records an event before each stage
 static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s, bool from_resync, int *nstage,
@@ -1281,10 +1341,36 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     int rc;
     bool small_write_on_side = false;
     hipEvent_t side_done = nullptr;
+    struct SideJoin { // joins a forked side stream to the run's stream on every way out of this function
+        hjd_batch::SideStream *ss = nullptr;
+        hipStream_t s = nullptr;
+        ~SideJoin()
+        {
+            if (ss && hipEventRecord(ss->done, ss->st) == hipSuccess) (void)hipStreamWaitEvent(s, ss->done, 0);
+        }
+    } joiner;
     const int nrep = b->dec->sync_launches - 1; // repair launches; the last one also leaves k_write's totals
     if (!from_resync) {
         if ((rc = mark("unstuff"))) return rc; // k_unstuff_count also clears the per-image state
         if (hjd_launch_unstuff(P, r.nchunk, s)) return HJD_ERR_INTERNAL;
+        // the images with a small workgroup of their own: beside the large ones when the range holds both kinds.  The side stream
+        // forks HERE, right behind the unstuff stage: the thumbnails' kernels do not wait for another run's k_sync (the waits
+        // below concern the large synchronisation kernel only)
+        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
+        // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
+        // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
+        // joins before it
+        small_write_on_side = ss && nrep == 0 && !r.side_feeds_big;
+        if (ss) {
+            if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->st, ss->fork, 0) != hipSuccess) return HJD_ERR_INTERNAL;
+            joiner.ss = ss; // from here on every return joins the side stream to `s` (include/hjd.h: work on library streams is joined
+                            // before hjd_batch_run returns — also when a launch fails half-way)
+            joiner.s = s;
+            if (hjd_launch_sync(P, r.nssyncwg, 3, ss->st)) return HJD_ERR_INTERNAL;
+            if (hjd_launch_sync_seq(P, r.nseq, ss->st)) return HJD_ERR_INTERNAL;
+            if (small_write_on_side && hjd_launch_write(P, r.nswritewg, ss->st, 1)) return HJD_ERR_INTERNAL;
+            if (hipEventRecord(ss->done, ss->st) != hipSuccess) return HJD_ERR_INTERNAL;
+        }
         // staggered ranges (batch_enqueue): this range's synchronisation — a latency chain that leaves most issue slots
         // empty — starts when the previous range has finished its own, so that it runs beside that range's final pass and
         // IDCT instead of beside three other synchronisation kernels
@@ -1304,27 +1390,16 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
             conc_record = d->conc_ev[k & 15];
         }
         if ((rc = mark("huff_sync"))) return rc;
-        // the images with a small workgroup of their own: beside the large ones when the range holds both kinds
-        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
-        // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
-        // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
-        // joins before it
-        small_write_on_side = ss && nrep == 0 && !r.side_feeds_big;
-        if (ss) {
-            if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->st, ss->fork, 0) != hipSuccess) return HJD_ERR_INTERNAL;
-            if (hjd_launch_sync(P, r.nssyncwg, 3, ss->st)) return HJD_ERR_INTERNAL;
-            if (hjd_launch_sync_seq(P, r.nseq, ss->st)) return HJD_ERR_INTERNAL;
-            if (small_write_on_side && hjd_launch_write(P, r.nswritewg, ss->st, 1)) return HJD_ERR_INTERNAL;
-            if (hipEventRecord(ss->done, ss->st) != hipSuccess) return HJD_ERR_INTERNAL;
-        }
         if (hjd_launch_sync(P, r.nsyncwg, 0, s)) return HJD_ERR_INTERNAL;
+        // the gate for other runs' synchronisation kernels is THIS kernel's end, not the small kernels' (recorded before the join)
+        if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (ss && !small_write_on_side) {
             if (hipStreamWaitEvent(s, ss->done, 0) != hipSuccess) return HJD_ERR_INTERNAL;
+            joiner.ss = nullptr; // joined
         } else if (!ss && (hjd_launch_sync(P, r.nssyncwg, 3, s) || hjd_launch_sync_seq(P, r.nseq, s))) {
             return HJD_ERR_INTERNAL;
         }
         side_done = ss ? ss->done : nullptr;
-        if (conc_record && hipEventRecord(conc_record, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (record_stagger && stagger_after == 1 && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
         if (nrep > 0 && (rc = mark("huff_repair"))) return rc;
         for (int l = 0; l < nrep; l++)
@@ -1337,6 +1412,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
     if (small_write_on_side) {
         if (hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return HJD_ERR_INTERNAL; // the side stream joins here
+        joiner.ss = nullptr;
     } else if (hjd_launch_write(P, r.nswritewg, s, 1)) {
         return HJD_ERR_INTERNAL;
     }
@@ -1541,12 +1617,12 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             bool stale = false;
             for (auto &st : b->state) stale |= (st.flags & HJD_FLAG_NOT_CONVERGED) != 0;
             if (!stale) break;
-            if (getenv("HJD_VERBOSE"))
+            if (b->dec->verbose)
                 for (size_t k = 0; k < b->state.size(); k++)
                     if (b->state[k].flags & HJD_FLAG_NOT_CONVERGED)
                         fprintf(stderr, "hjd: attempt %d image %zu flags %#x sync rounds %u (max %u) decodes %u\n", attempt, k, b->state[k].flags,
                                 b->state[k].sync_iters, b->state[k].sync_iters_max, b->state[k].sync_decodes);
-            if (attempt >= (getenv("HJD_MAX_RESYNC") ? atoi(getenv("HJD_MAX_RESYNC")) : 4096)) { // (the knob: diagnostics)
+            if (attempt >= b->dec->max_resync) { // (HJD_MAX_RESYNC: diagnostics)
                 overall = HJD_ERR_INTERNAL;
                 break;
             }
@@ -1671,6 +1747,17 @@ extern "C" int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, siz
     if (cap_words < n) return -1;
     if (hipMemcpy(dst, b->d_dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)b->nsyncwg;
+}
+
+extern "C" int hjd_batch_path_counts(const hjd_batch *b, uint32_t *counts4)
+{
+    if (!b || !counts4) return HJD_ERR_ARG;
+    counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
+    for (const HjdImage &im : b->img) {
+        counts4[im.sync_small == 2u ? 0 : (im.sync_small == 1u ? 1 : 2)]++;
+        counts4[3] += im.write_small ? 1u : 0u;
+    }
+    return HJD_OK;
 }
 
 extern "C" int hjd_batch_resync_count(const hjd_batch *b) { return b ? b->resyncs : -1; }

@@ -81,7 +81,9 @@ typedef struct hjd_jpeg_data {
     const uint8_t *stream;     /* stHuffmanData::m_stream: first entropy-coded byte (openjpg.cpp:220-223) */
     size_t stream_len;
     int restart_interval;      /* stHuffmanData::m_restart_interval: only tested ">0" (loadjpg.cpp:535,631) */
-    unsigned restart_mcus;     /* DRI payload Ri (the reference never reads it; needed to find intervals) */
+    unsigned restart_mcus;     /* DRI payload Ri when the caller knows it; 0 = not known — the reference never stores it
+                                * (openjpg.cpp:441-446), so its unmodified host passes 0: the markers are then taken where the scan
+                                * holds them, exactly as the reference's own checks do (it never counts MCUs, loadjpg.cpp:535-550) */
     /* frame header (stImageInfo, openjpg.h:11-17) */
     unsigned width, height;
     uint8_t hfactor, vfactor;  /* m_hFactor[cY], m_vFactor[cY] */
@@ -130,8 +132,15 @@ typedef struct hjd_options {
                           * taken by the standard's rule (no DIRTY verdicts), DC codes of 16 bits accepted, IDCT with the
                           * true cosines and round-to-nearest, colour conversion with the JFIF constants and rounding.
                           * Chroma stays nearest-neighbour.  0 = byte-identical to the reference. */
-    int reserved[2];
+    int debug_flags;     /* test switches (HJD_DBG_*): they select among paths that must all give the same bytes; 0 in production */
+    int reserved;
 } hjd_options;
+/* hjd_options.debug_flags */
+#define HJD_DBG_NO_SMALL_SYNC 1     /* no one-wave synchronisation / final-pass workgroups for small images */
+#define HJD_DBG_NO_SEQ_SYNC 2       /* no one-lane-per-image synchronisation of thumbnails */
+#define HJD_DBG_NO_SEG_EMULATION 4  /* dirty restart streams: the one-lane emulation kernel only */
+#define HJD_DBG_SIBLINGS(n) ((((n) + 1) & 15) << 8)  /* exactly n sibling trajectories (0..11) instead of the choice by launch size */
+#define HJD_DBG_SEG_CUT(n) (((n) & 0x7FFF) << 16)    /* emulation: a segment is cut off after exactly n blocks (0 = default) */
 
 hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt /* may be NULL */);
 void hjd_decoder_destroy(hjd_decoder *d);
@@ -143,6 +152,11 @@ int hjd_device_count(void);
 hjd_batch *hjd_batch_prepare(hjd_decoder *d, int n, const uint8_t *const *jpg, const size_t *jpg_len,
                              int out_format, int *status);
 void hjd_batch_destroy(hjd_batch *b);
+/* The same for images whose headers the caller has parsed — the batch-level twin of hjd_jpeg_decode_hw (loadjpg.h:180): jdata[i]
+ * as that call takes it (width / height / factors inside the struct), validated like a parsed header.  restart_mcus may be 0 with
+ * restart_interval > 0 (what an unmodified reference host knows, openjpg.cpp:441-446): the restart markers are then taken where
+ * the scan holds them, as the reference does (loadjpg.cpp:535-550). */
+hjd_batch *hjd_batch_prepare_parsed(hjd_decoder *d, int n, const hjd_jpeg_data *jdata, int out_format, int *status);
 
 /* Enqueue the whole decode (all kernels) on `hip_stream` (a hipStream_t, may be NULL = default
  * stream).  Asynchronous; inputs and outputs stay in HBM.  Work the library puts on streams of its own (ranges of a split
@@ -184,6 +198,9 @@ int hjd_batch_sync_stats(const hjd_batch *b, int i, uint32_t *stats4);
  * every synchronisation workgroup of the last run (32 words per workgroup: clock, tag pairs; tools/sync_profile.py).  Returns the
  * number of workgroups, or -1. */
 int hjd_debug_sync_profile(hjd_batch *b, unsigned long long *dst, size_t cap_words);
+/* Which kernels the batch's images were laid out for: counts4 = {images synchronised by k_sync_seq (one lane per image), by
+ * k_sync_small (one wave), by the large k_sync; images whose final pass runs in k_write_small}. */
+int hjd_batch_path_counts(const hjd_batch *b, uint32_t *counts4);
 /* Number of host-driven re-synchronisation rounds hjd_batch_finish had to run since prepare
  * (0 in normal operation: the warm-up subsequences of every synchronisation workgroup settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);

@@ -3,8 +3,8 @@
  * header parser (JpegParseHeader, openjpg.cpp:478) and replace only the HLS top function (JpegDecodeHW,
  * loadjpg.h:180) by libhjd.so.  Integration glue, header-only; it needs the REFERENCE's headers (loadjpg.h,
  * openjpg.h) on the include path and is therefore not compiled into the library.  INTEGRATION.md §2 shows its
- * use; tests/test_reference_shim.py compiles it against the reference's sources (build container only) and
- * compares what it produces with hjd_parse_header.
+ * use; the test recipe builds the reference's unchanged host around it (refhost_hjd, run on the GPU by
+ * tests/test_gpu_parity.py), and tests/test_reference_shim.py compares what it hands over with hjd_parse_header.
  */
 #ifndef HJD_REFERENCE_SHIM_H
 #define HJD_REFERENCE_SHIM_H
@@ -24,10 +24,13 @@ static inline size_t hjd_shim_scan_length(const unsigned char *s, size_t cap)
     return cap;
 }
 
-/* stJpegData (loadjpg.h:157-171) + stImageInfo (openjpg.h:11-17) -> hjd_jpeg_data: pointers and lengths instead of
- * fixed-capacity arrays.  dri_mcus = the DRI payload Ri, which the reference never stores (openjpg.cpp:441-446
- * keeps the segment LENGTH); pass 0 when the file has no DRI. */
-static inline void hjd_shim_from_reference(const stJpegData *jd, const stImageInfo *ji, unsigned dri_mcus, hjd_jpeg_data *o)
+/* stJpegData (loadjpg.h:157-171) -> hjd_jpeg_data: pointers and lengths instead of fixed-capacity arrays.  Width, height and the
+ * luma factors are the ones JpegDecodeHW is called with (openjpg.cpp:655): the struct does not hold them.  dri_mcus = the DRI
+ * payload Ri, which the reference never stores (openjpg.cpp:441-446 keeps the segment LENGTH): a host that has not been changed
+ * passes 0, and the library then takes the restart markers where the scan holds them — as the reference does
+ * (loadjpg.cpp:535-550). */
+static inline void hjd_shim_from_reference_args(const stJpegData *jd, unsigned int height, unsigned int width, unsigned char hF,
+                                                unsigned char vF, unsigned dri_mcus, hjd_jpeg_data *o)
 {
     memset(o, 0, sizeof *o);
     for (int c = cY; c <= cCr; c++) {
@@ -53,20 +56,37 @@ static inline void hjd_shim_from_reference(const stJpegData *jd, const stImageIn
     o->stream_len = hjd_shim_scan_length(jd->m_Huffman.m_stream, STREAM_SIZE);
     o->restart_interval = jd->m_Huffman.m_restart_interval; /* tested "> 0" only (loadjpg.cpp:535) */
     o->restart_mcus = dri_mcus;
-    o->width = ji->m_width;
-    o->height = ji->m_height;
-    o->hfactor = ji->m_hFactor[cY];
-    o->vfactor = ji->m_vFactor[cY];
+    o->width = width;
+    o->height = height;
+    o->hfactor = hF;
+    o->vfactor = vF;
 }
 
-/* Drop-in body for the reference's JpegDecodeHW: same arguments, same 0 on success (the reference returns 0
- * always; here a refused or corrupt input gives -1 and hjd_last_status() says why). */
-static inline int hjd_shim_jpeg_decode_hw(stJpegData *jdata, const stImageInfo *ji, unsigned dri_mcus, unsigned int h, unsigned int w,
-                                          unsigned char hF, unsigned char vF)
+/* The same from the parser's two structs (stImageInfo, openjpg.h:11-17), for hosts that have them at hand. */
+static inline void hjd_shim_from_reference(const stJpegData *jd, const stImageInfo *ji, unsigned dri_mcus, hjd_jpeg_data *o)
+{
+    hjd_shim_from_reference_args(jd, ji->m_height, ji->m_width, ji->m_hFactor[cY], ji->m_vFactor[cY], dri_mcus, o);
+}
+
+/* Drop-in BODY for the reference's JpegDecodeHW (loadjpg.h:180): same arguments, nothing else needed — host/reference_decodehw.cpp
+ * is exactly `int JpegDecodeHW(...) { return hjd_shim_jpeg_decode_hw(...); }`, linked with the reference's unchanged main.cpp and
+ * openjpg.cpp in place of loadjpg.cpp.  Returns 0 on success like the reference (which returns 0 always); a refused or corrupt
+ * input gives -1 and hjd_last_status() says why. */
+static inline int hjd_shim_jpeg_decode_hw(stJpegData *jdata, unsigned int jpeg_img_height, unsigned int jpeg_img_width,
+                                          unsigned char hFactor, unsigned char vFactor)
 {
     hjd_jpeg_data d;
-    hjd_shim_from_reference(jdata, ji, dri_mcus, &d);
-    return hjd_jpeg_decode_hw(&d, h, w, hF, vF, jdata->m_rgb) == HJD_OK ? 0 : -1; /* same argument order */
+    hjd_shim_from_reference_args(jdata, jpeg_img_height, jpeg_img_width, hFactor, vFactor, 0u, &d);
+    return hjd_jpeg_decode_hw(&d, jpeg_img_height, jpeg_img_width, hFactor, vFactor, jdata->m_rgb) == HJD_OK ? 0 : -1; /* same argument order */
+}
+
+/* ... and for a host that was taught to keep Ri (one line at openjpg.cpp:441-446) */
+static inline int hjd_shim_jpeg_decode_hw_ri(stJpegData *jdata, unsigned dri_mcus, unsigned int h, unsigned int w, unsigned char hF,
+                                             unsigned char vF)
+{
+    hjd_jpeg_data d;
+    hjd_shim_from_reference_args(jdata, h, w, hF, vF, dri_mcus, &d);
+    return hjd_jpeg_decode_hw(&d, h, w, hF, vF, jdata->m_rgb) == HJD_OK ? 0 : -1;
 }
 
 #endif /* HJD_REFERENCE_SHIM_H */

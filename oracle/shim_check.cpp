@@ -13,12 +13,11 @@
 
 #include "hjd_reference_shim.h"
 
-static stImageInfo *g_info;
 static unsigned g_dri;
 
 int JpegDecodeHW(stJpegData *jdata, unsigned int h, unsigned int w, unsigned char hF, unsigned char vF)
 {
-    return hjd_shim_jpeg_decode_hw(jdata, g_info, g_dri, h, w, hF, vF);
+    return hjd_shim_jpeg_decode_hw_ri(jdata, g_dri, h, w, hF, vF);
 }
 
 #define DIFF(what)                              \
@@ -39,7 +38,6 @@ int main(int argc, char **argv)
 
     stJpegData *jd = new stJpegData();
     stImageInfo *ji = new stImageInfo();
-    g_info = ji;
     fclose(stdout); // the reference's parser prints
     stdout = fopen("/dev/null", "w");
     if (JpegParseHeader(jd, ji, buf.data(), (unsigned)n) < 0) return 3;

@@ -33,6 +33,23 @@ KNOBS = [{}, {"HJD_PHASE_WORDS": "2"}, {"HJD_PHASE_WORDS": "4", "HJD_WRITE_WINDO
          {"HJD_NO_SEG_EMULATION": "1"}, {"HJD_SEG_CUT": "8"}]
 
 
+def split_knobs(hjd, knobs):
+    """(environment proper, hjd_options.debug_flags): the test switches are options of the decoder (include/hjd.h: HJD_DBG_*)."""
+    env = dict(knobs)
+    f = 0
+    if env.pop("HJD_NO_SMALL_SYNC", None):
+        f |= hjd.DBG_NO_SMALL_SYNC
+    if env.pop("HJD_NO_SEQ_SYNC", None):
+        f |= hjd.DBG_NO_SEQ_SYNC
+    if env.pop("HJD_NO_SEG_EMULATION", None):
+        f |= hjd.DBG_NO_SEG_EMULATION
+    if "HJD_SIBLINGS" in env:
+        f |= hjd.dbg_siblings(int(env.pop("HJD_SIBLINGS")))
+    if "HJD_SEG_CUT" in env:
+        f |= hjd.dbg_seg_cut(int(env.pop("HJD_SEG_CUT")))
+    return env, f
+
+
 def make(args):
     seed, max_side = args
     rng = np.random.default_rng(seed)
@@ -86,10 +103,29 @@ def main():
             for k in list(os.environ):
                 if k.startswith("HJD_") and k not in ("HJD_BENCH_BACKEND",):
                     del os.environ[k]
-            os.environ.update(knobs)
+            env, flags = split_knobs(hjd, knobs)
+            os.environ.update(env)
             streams, launches = int(rng.choice([0, 0, 2, 3])), int(rng.choice([0, 0, 2, 3]))
-            dec = hjd.Decoder(0, subseq_bits=bits, streams=streams, sync_launches=launches)
-            st, outs = dec.decode([it[0] for it in items])
+            dec = hjd.Decoder(0, subseq_bits=bits, streams=streams, sync_launches=launches, debug_flags=flags)
+            no_ri = rng.random() < 0.3   # round 5: the HW/SW cut as an unmodified reference host drives it — parsed headers, Ri withheld
+            if no_ri:
+                jds = []
+                for it in items:
+                    pst, jd = hjd.parse_header(it[0])
+                    jd.restart_mcus = 0
+                    jds.append((pst, jd))
+                good_idx = [k for k, (pst, _) in enumerate(jds) if pst == 0]
+                b = dec.prepare_parsed([jds[k][1] for k in good_idx], keep_alive=[it[0] for it in items])
+                b.run()
+                bst = b.finish()
+                st, outs = [jds[k][0] for k in range(len(items))], [None] * len(items)
+                for i, k in enumerate(good_idx):
+                    st[k] = bst[i]
+                    outs[k] = b.download(i) if bst[i] == 0 else None
+                b.close()
+                knobs = dict(knobs, no_ri=1)
+            else:
+                st, outs = dec.decode([it[0] for it in items])
             dec.close()
             for k, (jpg, rc, orgb) in enumerate(items):
                 good = (st[k] == 0 and np.array_equal(outs[k], orgb)) if rc == 0 else st[k] != 0

@@ -27,6 +27,24 @@ def dec(hjd):
     d.close()
 
 
+def _dbg(hjd, env):
+    """Test switches by their old names -> (environment proper, hjd_options.debug_flags).  The switches that select among paths
+    that must give the same bytes are options of the decoder (include/hjd.h: HJD_DBG_*), not variables of the process."""
+    env = dict(env)
+    f = 0
+    if env.pop("HJD_NO_SMALL_SYNC", None):
+        f |= hjd.DBG_NO_SMALL_SYNC
+    if env.pop("HJD_NO_SEQ_SYNC", None):
+        f |= hjd.DBG_NO_SEQ_SYNC
+    if env.pop("HJD_NO_SEG_EMULATION", None):
+        f |= hjd.DBG_NO_SEG_EMULATION
+    if "HJD_SIBLINGS" in env:
+        f |= hjd.dbg_siblings(int(env.pop("HJD_SIBLINGS")))
+    if "HJD_SEG_CUT" in env:
+        f |= hjd.dbg_seg_cut(int(env.pop("HJD_SEG_CUT")))
+    return env, f
+
+
 def _ok_fixtures(golden, restart=("none",)):
     d, man = golden
     return [(n, e, open(os.path.join(d, n), "rb").read()) for n, e in sorted(man.items())
@@ -195,25 +213,23 @@ def test_thumbnail_batches_take_the_small_kernels(hjd):
         rc, orgb, _, _, _ = T.oracle_decode(j)
         want[j] = (rc, orgb)
     for env in ({}, {"HJD_NO_SEQ_SYNC": "1"}, {"HJD_NO_SEQ_SYNC": "1", "HJD_NO_SMALL_SYNC": "1"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            for streams in (0, 3):
-                d = hjd.Decoder(0, streams=streams)
-                st, outs = d.decode(jpgs)
-                for j, s_, o in zip(jpgs, st, outs):
-                    rc, orgb = want[j]
-                    if rc == 0:
-                        assert s_ == 0 and np.array_equal(o, orgb), (env, streams, len(j))
-                    else:
-                        assert s_ != 0
-                d.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
+        _, flags = _dbg(hjd, env)
+        for streams in (0, 3):
+            d = hjd.Decoder(0, streams=streams, debug_flags=flags)
+            b = d.prepare(jpgs)
+            pc = b.path_counts()   # the paths under test were really laid out (and really switched off)
+            assert (pc["sync_seq"] > 300) == (not env) and (pc["sync_small"] > (0 if not env else 300)) == (len(env) < 2), (env, pc)
+            assert (pc["write_small"] > 300) == (len(env) < 2) and pc["sync_large"] >= 3, (env, pc)
+            b.run()
+            st = b.finish()
+            for k_, (j, s_) in enumerate(zip(jpgs, st)):
+                rc, orgb = want[j]
+                if rc == 0:
+                    assert s_ == 0 and np.array_equal(b.download(k_), orgb), (env, streams, len(j))
                 else:
-                    os.environ[k] = v
+                    assert s_ != 0
+            b.close()
+            d.close()
 
 
 def test_sibling_trajectories_change_nothing_but_the_time(hjd):
@@ -222,26 +238,18 @@ def test_sibling_trajectories_change_nothing_but_the_time(hjd):
     jpgs = [T.synth_jpeg(3840, 2160, 1000, 85, 2, 2), T.synth_jpeg(1920, 1080, 501, 85, 1, 1), T.synth_jpeg(1000, 700, 4243, 90, 2, 1, 25, 9.0),
             T.encode_jpeg_ex(T.synth_rgb(1600, 1200, 5, 12.0), 80, 2, 2, 0, True, T.HUFF_FOUR_OPTIMISED)]
     want = [T.oracle_decode(j)[1] for j in jpgs]
-    old = os.environ.get("HJD_SIBLINGS")
-    try:
-        for sib in ("0", "1", "3", "5", "8", "11"):
-            os.environ["HJD_SIBLINGS"] = sib
-            for bits in (0, 1024, 4096):
-                d = hjd.Decoder(0, subseq_bits=bits)
-                b = d.prepare(jpgs)
-                for _ in range(2):  # the second run re-uses the flags of the first (epochs)
-                    b.run()
-                    st = b.finish()
-                assert st == [0] * len(jpgs) and b.resync_count() == 0, (sib, bits, st)
-                for k, w in enumerate(want):
-                    assert np.array_equal(b.download(k), w), (sib, bits, k)
-                b.close()
-                d.close()
-    finally:
-        if old is None:
-            os.environ.pop("HJD_SIBLINGS", None)
-        else:
-            os.environ["HJD_SIBLINGS"] = old
+    for sib in (0, 1, 3, 5, 8, 11):
+        for bits in (0, 1024, 4096):
+            d = hjd.Decoder(0, subseq_bits=bits, debug_flags=hjd.dbg_siblings(sib))
+            b = d.prepare(jpgs)
+            for _ in range(2):  # the second run re-uses the flags of the first (epochs)
+                b.run()
+                st = b.finish()
+            assert st == [0] * len(jpgs) and b.resync_count() == 0, (sib, bits, st)
+            for k, w in enumerate(want):
+                assert np.array_equal(b.download(k), w), (sib, bits, k)
+            b.close()
+            d.close()
 
 
 @pytest.mark.parametrize("bits", [64, 128, 256, 512, 1024, 4096, 16384])
@@ -281,15 +289,17 @@ def test_dense_records_at_small_subsequences(hjd, bits):
 def test_tuning_knobs_never_change_a_byte(hjd, golden, env):
     """Window size (= checkpoint spacing = what one k_write lane decodes), windows per k_write lane, sibling trajectories forced on,
     the front-end concurrency limit, staggered ranges, in-stream repair launches, none or a single warm-up
-    subsequence per synchronisation workgroup, the emulation of dirty restart streams by one lane or with its segments cut short: tuning only.  The knobs are read when a decoder is created."""
+    subsequence per synchronisation workgroup, the emulation of dirty restart streams by one lane or with its segments cut short: tuning only.
+    Environment variables are read when a decoder is created; the test switches among them are hjd_options.debug_flags (_dbg)."""
     fx = _ok_fixtures(golden, restart=("none", "clean", "dirty"))
     big = [T.synth_jpeg(1280, 720, 4242, 85, 2, 2), T.synth_jpeg(1000, 700, 4243, 90, 1, 1, 25, 9.0)]
     want = [T.oracle_decode(j)[1] for j in big]
+    env, flags = _dbg(hjd, env)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         for bits, streams, launches in ((0, 0, 0), (512, 3, 3), (4096, 2, 2)):
-            d = hjd.Decoder(0, subseq_bits=bits, streams=streams, sync_launches=launches)
+            d = hjd.Decoder(0, subseq_bits=bits, streams=streams, sync_launches=launches, debug_flags=flags)
             st, outs = d.decode([f[2] for f in fx] + big)
             for (name, ent, data), s, o in zip(fx, st, outs):
                 assert s == 0 and hashlib.sha256(o.tobytes()).hexdigest() == ent["rgb_sha256"], (name, env, bits)
@@ -367,7 +377,7 @@ def test_restart_synthetic_matches_oracle_or_is_refused(hjd, dec, w, h, hf, vf, 
 def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
     """Restart streams outside the clean-resync domain: the emulation runs parallel over the places where the
     reference can resynchronise (csrc/hjd_seq.hip: k_seg_*), one lane per (candidate, block-in-MCU label); the one-lane kernel
-    stays as the fallback (HJD_NO_SEG_EMULATION=1 forces it).  Both must give the oracle's bytes, or both the oracle's refusal."""
+    stays as the fallback (HJD_DBG_NO_SEG_EMULATION forces it).  Both must give the oracle's bytes, or both the oracle's refusal."""
     specs = [(320, 240, 1, 1, 2, 0.5, 4105), (320, 240, 1, 1, 3, 2.0, 4110), (320, 240, 2, 1, 1, 4.0, 4119), (320, 240, 1, 2, 3, 4.0, 4159),
              (250, 187, 2, 1, 3, 0.5, 4205), (250, 187, 4, 1, 3, 0.5, 4253), (512, 384, 1, 1, 2, 0.5, 4265), (512, 384, 2, 1, 7, 0.5, 4289),
              (512, 384, 2, 2, 2, 4.0, 4299), (512, 384, 1, 2, 2, 2.0, 4314), (512, 384, 2, 1, 2, 0.5, 4281), (250, 187, 1, 1, 1, 0.5, 4181),
@@ -389,22 +399,16 @@ def test_segment_parallel_emulation_equals_the_one_lane_kernel(hjd):
     assert sum(1 for w_ in want if w_[0] == 0 and w_[4].resyncs_dirty) >= 10 and sum(1 for w_ in want if w_[0] != 0) >= 2   # the oracle took the dirty branches
     res = {}
     for knob in (None, "1", "cut"):
-        if knob == "cut":
-            os.environ["HJD_SEG_CUT"] = "2"   # every chain soon meets a cut-off segment: tried in parallel, then left to the one-lane kernel
-        elif knob:
-            os.environ["HJD_NO_SEG_EMULATION"] = knob
-        try:
-            d = hjd.Decoder(0)
-            b = d.prepare(jpgs)
-            b.run()
-            b.run()   # a second run of the same batch: every per-run list is rebuilt on the device
-            st = b.finish()
-            outs = [b.download(k) if s == 0 else None for k, s in enumerate(st)]
-            res[knob] = (st, outs, b.sequential_count(), b.segment_count())
-            b.close(); d.close()
-        finally:
-            os.environ.pop("HJD_NO_SEG_EMULATION", None)
-            os.environ.pop("HJD_SEG_CUT", None)
+        # "cut": every chain soon meets a cut-off segment: tried in parallel, then left to the one-lane kernel
+        flags = hjd.dbg_seg_cut(2) if knob == "cut" else (hjd.DBG_NO_SEG_EMULATION if knob else 0)
+        d = hjd.Decoder(0, debug_flags=flags)
+        b = d.prepare(jpgs)
+        b.run()
+        b.run()   # a second run of the same batch: every per-run list is rebuilt on the device
+        st = b.finish()
+        outs = [b.download(k) if s == 0 else None for k, s in enumerate(st)]
+        res[knob] = (st, outs, b.sequential_count(), b.segment_count())
+        b.close(); d.close()
     for knob, (st, outs, nseq, nseg) in res.items():
         for k, (s, o, (orc, orgb, _, _, _)) in enumerate(zip(st, outs, want)):
             if orc == 0:
@@ -593,6 +597,128 @@ def test_reference_main_binary_runs_on_the_gpu(hjd, golden, tmp_path):
     ent = man["Lenna.jpg"]
     assert len(bmp) == ent["bmp_bytes"]
     assert hashlib.sha256(bmp).hexdigest() in (ent["bmp_sha256"], ent.get("bmp_sha256_masked"))
+
+
+def _mask_bmp_pad(bmp, w, h):
+    """BMP row-pad bytes 2 and 3 zeroed: the reference's WriteBMP24 writes them from the stack (openjpg.cpp:563-567;
+    tools/make_golden.py: bmp_sha256_masked)."""
+    pad = (4 - (3 * w) % 4) % 4
+    body = np.frombuffer(bmp, np.uint8)[54:].reshape(h, 3 * w + pad).copy()
+    if pad > 1:
+        body[:, 3 * w + 1:] = 0
+    return bmp[:54] + body.tobytes()
+
+
+@pytest.mark.parametrize("name", ["Lenna.jpg", "syn_256x192_420_q85_rst16.jpg", "syn_250x187_444_q85_rst4.jpg", "syn_250x187_420_q85_4opt_rst5.jpg",
+                                  "flat_64x64_444_rst1_dirty.jpg", "syn_250x187_422_q85_3dqt_6huff.jpg"])
+def test_reference_host_binary_runs_on_the_gpu(hjd, golden, tmp_path, name):
+    """BASELINE north_star's drop-in at the HW/SW cut, executed: the reference's main.cpp AND openjpg.cpp — its file read, its
+    JpegParseHeader (openjpg.cpp:371-496), its WriteBMP24 (:504-570) — compiled where they lie, unchanged, with JpegDecodeHW
+    (loadjpg.h:180, called at openjpg.cpp:655) defined by hls-jpeg-decoder_amd/host/reference_decodehw.cpp through include/hjd_reference_shim.h on top of
+    libhjd.so; loadjpg.cpp is not linked (oracle/Makefile: _ref/refhost_hjd).  main.cpp:28-36 converts ../../../../data/Lenna.jpg
+    (whatever file sits there) into ../../../../data/out.bmp: the BMP the reference's own writer wrote must be the one the wholly
+    compiled reference wrote.  The restart fixtures reach the library WITHOUT Ri (openjpg.cpp:441-446 keeps the segment length):
+    clean ones through the parallel path, the dirty one through the emulation."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "refhost_hjd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refhost_hjd is built in the build container only (make -C oracle ref)")
+    d, man = golden
+    data = tmp_path / "data"
+    cwd = tmp_path / "a" / "b" / "c" / "d"
+    data.mkdir()
+    cwd.mkdir(parents=True)
+    shutil.copy(os.path.join(d, name), data / "Lenna.jpg")
+    r = subprocess.run([exe], cwd=str(cwd), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "hjd:" not in r.stderr, r.stderr[-2000:]   # the library reports refusals there
+    bmp = (data / "out.bmp").read_bytes()
+    ent = man[name]
+    assert len(bmp) == ent["bmp_bytes"]
+    assert hashlib.sha256(_mask_bmp_pad(bmp, ent["width"], ent["height"])).hexdigest() == ent["bmp_sha256_masked"], name
+
+
+@pytest.mark.parametrize("case", [(1920, 1080, 500, 85, 2, 2, 0, 6.0), (1920, 1080, 700, 85, 2, 2, 120, 6.0), (1920, 1080, 701, 85, 1, 1, 16, 6.0),
+                                  (3840, 2160, 1003, 85, 2, 2, 0, 6.0)])
+def test_reference_host_binary_big_capacity(hjd, tmp_path, case):
+    """The same drop-in at the capacity the full-size inputs need (the three #defines of loadjpg.h:55-57 enlarged, as for
+    oracle/_ref/ref_big; argv driver instead of main.cpp's fixed paths: _ref/refhost_hjd_big): one 1080p image, one 4K bench input,
+    1080p with one MCU row per restart interval (clean) and 1080p 4:4:4 with 16-MCU intervals (the reference leaves the clean-resync
+    domain four times on it) — the BMP its WriteBMP24 wrote hashes to what the wholly compiled reference wrote
+    (tests/golden/large_manifest.json)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "refhost_hjd_big")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refhost_hjd_big is built in the build container only (make -C oracle ref)")
+    w, h, seed, q, hf, vf, rst, sigma = case
+    j = T.synth_jpeg(w, h, seed, q, hf, vf, rst, sigma)
+    ent = T.large_golden(w, h, seed, q, hf, vf, j, rst)
+    if ent is None:
+        pytest.skip("regenerated input differs from the one the reference was run on (other libm)")
+    jp, bp = tmp_path / "in.jpg", tmp_path / "out.bmp"
+    jp.write_bytes(j)
+    r = subprocess.run("ulimit -s unlimited; exec %s %s %s > /dev/null" % (exe, jp, bp), shell=True, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "hjd:" not in r.stderr, r.stderr[-2000:]
+    assert hashlib.sha256(bp.read_bytes()).hexdigest() == ent["bmp_sha256"], case
+
+
+def test_decode_hw_without_the_restart_interval(hjd, dec, golden):
+    """The HW/SW cut as an unmodified reference host drives it: restart_interval > 0 (the DRI segment's length, openjpg.cpp:441-446)
+    and restart_mcus = 0 — Ri never reaches JpegDecodeHW.  The library then takes the markers where the scan holds them (host count
+    sizes the slabs; the final pass asks only what the reference's check asks, loadjpg.cpp:535-550): clean streams stay on the parallel
+    path (no emulation, no host re-synchronisation), dirty ones go through the emulation; every output equals the oracle's / the
+    compiled reference's."""
+    d, man = golden
+    names = ["syn_256x192_420_q85_rst16.jpg", "syn_250x187_444_q85_rst4.jpg", "syn_250x187_422_q85_rst1.jpg", "syn_250x187_420_q85_4opt_rst5.jpg",
+             "flat_64x64_444_rst1_dirty.jpg"]
+    jpgs = [open(os.path.join(d, n), "rb").read() for n in names]
+    jpgs += [T.synth_jpeg(1920, 1080, 700, 85, 2, 2, 120, 6.0), T.synth_jpeg(1920, 1080, 701, 85, 1, 1, 16, 6.0),
+             T.synth_jpeg(640, 480, 77 + 1, 85, 2, 2, 1, 6.0), T.synth_jpeg(128, 128, 5, 85, 2, 2, 0xFFFF, 6.0)]
+    extra = bytearray(jpgs[5])   # an RSTn pair where no encoder puts one: in the middle of an interval (the reference resynchronises there)
+    sos = extra.index(b"\xff\xda")
+    at = sos + 14 + (len(extra) - sos) // 2
+    while extra[at - 1] == 0xFF or extra[at] == 0xFF:
+        at += 1
+    extra[at:at] = b"\xff\xd3"
+    jpgs.append(bytes(extra))
+    want = [T.oracle_decode(j) for j in jpgs]
+    jds = []
+    for j in jpgs:
+        st, jd = hjd.parse_header(j)
+        assert st == 0 and jd.restart_interval > 0 and jd.restart_mcus > 0
+        jd.restart_mcus = 0
+        jds.append(jd)
+    L = hjd.lib()
+    # (a) the single-image entry point, as the shim calls it
+    for k, (j, jd, (orc, orgb, _, _, ost)) in enumerate(zip(jpgs, jds, want)):
+        out = np.zeros((jd.height, jd.width, 3), np.uint8)
+        rc = L.hjd_jpeg_decode_hw(ctypes.byref(jd), jd.height, jd.width, jd.hfactor, jd.vfactor, out.ctypes.data)
+        if orc == 0:
+            assert rc == 0 and np.array_equal(out, orgb), (k, rc)
+        else:
+            assert rc == hjd.HJD_ERR_CORRUPT, (k, rc, orc)
+    for n, o in zip(names, range(len(names))):
+        assert hashlib.sha256(want[o][1].tobytes()).hexdigest() == man[n]["rgb_sha256"]
+    # (b) the batch-level twin: which path every image took
+    clean = [k for k, w_ in enumerate(want) if w_[0] == 0 and w_[4].resyncs_dirty == 0]
+    dirty = [k for k, w_ in enumerate(want) if w_[0] == 0 and w_[4].resyncs_dirty != 0]
+    assert len(clean) >= 6 and len(dirty) >= 2, (clean, dirty)
+    for subset, expect_seq in ((clean, 0), (dirty, len(dirty)), (list(range(len(jpgs))), None)):
+        b = dec.prepare_parsed([jds[k] for k in subset], keep_alive=jpgs)
+        b.run()
+        st = b.finish()
+        for i, k in enumerate(subset):
+            if want[k][0] == 0:
+                assert st[i] == 0 and np.array_equal(b.download(i), want[k][1]), (k, st[i])
+            else:
+                assert st[i] == hjd.HJD_ERR_CORRUPT, (k, st[i])
+        assert b.resync_count() == 0
+        if expect_seq is not None:
+            assert b.sequential_count() == expect_seq, (subset, b.sequential_count())
+        if expect_seq:
+            assert b.segment_count() == expect_seq   # parallel over the resynchronisation points, not one lane per image
+        b.close()
 
 
 def test_reference_shaped_entry_points(hjd, golden):

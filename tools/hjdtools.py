@@ -214,7 +214,7 @@ def ref_convert(jpg_path, bmp_path, big=True, timeout=600):
 _LARGE = None
 
 
-def large_golden(w, h, seed, quality, hf, vf, jpg):
+def large_golden(w, h, seed, quality, hf, vf, jpg, rst=0):
     """Entry of tests/golden/large_manifest.json for this synthetic input, or None when there is none
     or when the regenerated input is not byte-identical to the one the reference was run on (another
     libm): the caller then falls back to the oracle and says so."""
@@ -224,7 +224,7 @@ def large_golden(w, h, seed, quality, hf, vf, jpg):
     if _LARGE is None:
         p = os.path.join(ROOT, "tests", "golden", "large_manifest.json")
         _LARGE = json.load(open(p)) if os.path.exists(p) else {}
-    ent = _LARGE.get("syn_%dx%d_s%d_q%d_%dx%d" % (w, h, seed, quality, hf, vf))
+    ent = _LARGE.get("syn_%dx%d_s%d_q%d_%dx%d" % (w, h, seed, quality, hf, vf) + ("_rst%d" % rst if rst else ""))
     if ent is None:
         return None
     if hashlib.sha256(jpg).hexdigest() != ent["jpg_sha256"]:
