@@ -3,6 +3,7 @@
 #   make oracle  -> oracle/libhjd_oracle.so            (CPU checker, tests only)
 #   make tools   -> tools/libhjd_enc.so                (test JPEG encoder)
 #   make ref     -> oracle/_ref/*                      (compiled reference; build container only)
+#   make sanitize -> build/fuzz_header (ASan + UBSan build of the host side: header walk, validation, table builder) and run it
 PKG = hls-jpeg-decoder_amd
 HIPCC ?= hipcc
 ARCH ?= gfx950
@@ -35,8 +36,18 @@ tools/libhjd_enc.so: tools/jpeg_enc.c
 ref:
 	$(MAKE) -C oracle ref
 
+# Sanitizer build of the host code that touches unchecked bytes (CPU only: GPU AddressSanitizer is not available on the pool).
+FUZZ_ITERS ?= 300000
+sanitize:
+	mkdir -p build
+	g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Wall \
+	  tests/fuzz_header.cpp $(PKG)/host/hjd_host.cpp -o build/fuzz_header
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1 build/fuzz_header $(FUZZ_ITERS) 20251005 \
+	  tests/golden/Lenna.jpg tests/golden/syn_250x187_422_q85_3dqt_6huff.jpg tests/golden/pil_250x187_444_q95_opt.jpg \
+	  tests/golden/syn_256x192_420_q85_rst16.jpg tests/golden/pil_progressive.jpg tests/golden/pil_gray.jpg tests/golden/syn_96x64_444_q60_3dqt_6perm.jpg
+
 clean:
 	rm -rf $(PKG)/lib $(PKG)/bin tools/libhjd_enc.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle tools ref clean
+.PHONY: all lib oracle tools ref sanitize clean

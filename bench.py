@@ -180,11 +180,13 @@ def dry_rank(args, rank, world):
         time.sleep(3600)
     if world > 1:
         shard.fail_fast("barrier", dist.barrier)
-    dt, px = shard.fail_fast("clock agreement", shard.agree, 0.001 * (rank + 1) * args.steps,
+    own_dt = 0.001 * (rank + 1) * args.steps
+    dt, px = shard.fail_fast("clock agreement", shard.agree, own_dt,
                              float(len(mine) * args.width * args.height), device="cpu")
+    per_rank = shard.fail_fast("per-rank times", shard.gather_per_rank, rank, -1, own_dt, args.steps, device="cpu")
     if rank == 0:
         print(json.dumps({"metric": "Mpixels/s JPEG->RGB (4:2:0 baseline batch)", "dry": True, "n_gpus": world, "steps": args.steps,
-                          "backend": backend, "ranks_seen": seen,
+                          "backend": backend, "ranks_seen": seen, "per_rank": per_rank,
                           "value": round(px * args.steps / dt / 1e6, 1), "ms_per_step": round(dt / args.steps * 1e3, 4),
                           "config": {"images_per_gpu": len(mine), "global_images": n_global}}), flush=True)
     if world > 1:
@@ -392,6 +394,7 @@ def main():
         e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
 
     adev = "cuda" if backend == "nccl" else "cpu"
+    per_rank = shard.fail_fast("per-rank times", shard.gather_per_rank, rank, local_rank, dt, args.steps, device=adev)  # before MAX replaces dt
     dt, total_pixels = shard.fail_fast("clock agreement", shard.agree, dt, pixels, device=adev)  # MAX of time, SUM of pixels
     spread_dt = [shard.fail_fast("clock agreement", shard.agree, x, 0.0, device=adev)[0] for x in spread_dt]
 
@@ -498,6 +501,7 @@ def main():
             "n_gpus": world,
             "backend": backend,        # process group the ranks met over: "nccl" (= RCCL), "gloo", or "none" for one rank
             "ranks_seen": seen,        # an all-reduce of ones over that group
+            "per_rank": per_rank,      # every rank's own time per step (value uses the MAX): a straggler is visible here
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),

@@ -27,8 +27,21 @@
 #pragma once
 #include <stdint.h>
 
-#define HJD_LUT_BITS 11
+// Index widths of the primary Huffman tables, swept in round 5 (profiles/r05_lut_sweep.txt; 64 x 4K bench, same box, interleaved):
+//   final pass 11 / 10 / 9 / 8 bits: 305 / 310 / 315.5 / 307 Gpixel/s (k_write alone 0.138 ms at every width).  What counts is
+//   k_write's LDS: 2-byte entries, four tables + the second-level tables are 17.2 / 9.6 / 6.9 / 8.7 KB for the Annex K tables
+//   (narrower primary tables need wider second-level ones: 9 is the minimum), and at 39.6 KB instead of 49.8 a final-pass
+//   workgroup fits on a CU BESIDE eight back-end workgroups (8 x 14.6 KB) and four of them fit a CU instead of three.
+//   synchronisation 11 / 10 / 9 bits: 305 / 301 / 301 — k_sync itself gets slower (0.286 / 0.306 / 0.322 ms: fewer two-symbol
+//   entries fit a narrower window, more second look-ups) and its 81 KB are not what the other kernels wait for.
+#ifndef HJD_LUT_BITS
+#define HJD_LUT_BITS 9         // primary table of the final pass (k_write) and of the emulation kernels: index bits
+#endif
+#ifndef HJD_LUT_BITS_S
+#define HJD_LUT_BITS_S 11      // ... of the synchronisation kernels (their entries are 4 bytes: 4 << HJD_LUT_BITS_S bytes of LDS per table)
+#endif
 #define HJD_LUT_SIZE (1 << HJD_LUT_BITS)
+#define HJD_LUT_SIZE_S (1 << HJD_LUT_BITS_S)
 #define HJD_SLOTS 6            // (component 0..2) * 2 + (0 = DC, 1 = AC)
 #define HJD_UNSTUFF_CHUNK 4096 // raw bytes per unstuff workgroup (256 lanes x 16 B)
 #ifndef HJD_SYNC_WG
@@ -49,7 +62,9 @@
 #define HJD_SEQ_MAX_BITS 65536u // scans up to this many bits go to k_sync_seq (one lane per image)
 #define HJD_WRITE_WG_SMALL 64   // lanes of the small final-pass workgroup (k_write_small: images with HjdImage::sync_small)
 #define HJD_ENT_CAP_SMALL 512u
+#ifndef HJD_ENT_CAP
 #define HJD_ENT_CAP 2048u      // block entries a final-pass workgroup collects in LDS before it writes them out together
+#endif
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
 #define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 
@@ -63,16 +78,19 @@
 //   code length 0: the code is longer than HJD_LUT_BITS; bits 5-15 = 1 + index of the secondary
 //   table for this prefix (0 = no code has this prefix).  Secondary tables are indexed by the next
 //   HJD_SEC_BITS bits and hold entries of the same format (length 0 = no such code).
-// 11 primary bits: on the q85 bench content 1.1 % of the AC symbols are longer than 10 bits but only
-// 0.2 % longer than 11, i.e. a 64-lane wave takes the second look-up in 12 % of its steps instead of 50 %.
+// (On the q85 bench content 1.1 % of the AC symbols are longer than 10 bits and 0.2 % longer than 11: the synchronisation loop,
+// whose step is a hand-scheduled chain, keeps 11 bits; the final pass, whose waves take a divergent branch or other in nearly every
+// iteration anyway, loses nothing measurable to the more frequent second look-up at 9.)
 #define HJD_SEC_BITS (16 - HJD_LUT_BITS)
 #define HJD_SEC_SIZE (1 << HJD_SEC_BITS)
+#define HJD_SEC_BITS_S (16 - HJD_LUT_BITS_S)
+#define HJD_SEC_SIZE_S (1 << HJD_SEC_BITS_S)
 #define HJD_MAX_SEC 512
 struct HjdTableSet {
     uint32_t nlut;       // distinct primary tables in use (identical DHT payloads share one)
     uint32_t nsec;       // secondary tables in use
     uint32_t slot_pack;  // 6 x 4 bits: slot (component*2 + isAC) -> primary table index
-    uint32_t pad;
+    uint32_t nsec_s;     // secondary tables of the synchronisation form (its primary index may be narrower: other prefixes)
     uint16_t lut[HJD_SLOTS][HJD_LUT_SIZE];
     uint16_t sec[HJD_MAX_SEC][1 << HJD_SEC_BITS];
     // The same tables in the form the synchronisation pass wants (it needs no values): bits 0-4 code length + value bits
@@ -82,8 +100,8 @@ struct HjdTableSet {
     // HJD_LUT_BITS window and the first symbol is neither an end-of-block nor a long code — else a copy of [0].  The decoder
     // takes [1] while the first symbol cannot end the block (z < 48: an AC advance is at most 16) and the second symbol still
     // starts inside the staging window.  On the q85 bench content 38 % of the look-ups go away.
-    uint16_t lut_s[HJD_SLOTS][HJD_LUT_SIZE][2];
-    uint16_t sec_s[HJD_MAX_SEC][1 << HJD_SEC_BITS];
+    uint16_t lut_s[HJD_SLOTS][HJD_LUT_SIZE_S][2];
+    uint16_t sec_s[HJD_MAX_SEC][1 << HJD_SEC_BITS_S];
 };
 
 struct HjdImage {

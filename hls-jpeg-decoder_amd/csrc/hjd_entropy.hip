@@ -64,7 +64,8 @@ __device__ __forceinline__ const uint32_t *row_base(const uint32_t *w, uint32_t 
 template <bool SYNC_FORM>
 __device__ __forceinline__ void load_tables(const HjdTableSet *ts, void *s_lut, void *s_sec)
 {
-    const uint32_t nl = ts->nlut * (HJD_LUT_SIZE * (SYNC_FORM ? 4 : 2) / 16), ns = ts->nsec * (HJD_SEC_SIZE * 2 / 16);
+    const uint32_t nl = ts->nlut * ((SYNC_FORM ? HJD_LUT_SIZE_S * 4 : HJD_LUT_SIZE * 2) / 16);
+    const uint32_t ns = SYNC_FORM ? ts->nsec_s * (HJD_SEC_SIZE_S * 2 / 16) : ts->nsec * (HJD_SEC_SIZE * 2 / 16);
     const uint4 *src = reinterpret_cast<const uint4 *>(SYNC_FORM ? &ts->lut_s[0][0][0] : &ts->lut[0][0]);
     uint4 *dst = reinterpret_cast<uint4 *>(s_lut);
     for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x) dst[k] = src[k];
@@ -77,8 +78,9 @@ __device__ __forceinline__ void load_tables(const HjdTableSet *ts, void *s_lut, 
 // the synchronisation form with its two entries per index
 __device__ __forceinline__ uint32_t table_pair(uint32_t slot_pack, uint32_t comp, uint32_t entry_bytes)
 {
-    const uint32_t dc = ((slot_pack >> (comp * 8u)) & 7u) * (HJD_LUT_SIZE * entry_bytes);
-    const uint32_t ac = ((slot_pack >> (comp * 8u + 4u)) & 7u) * (HJD_LUT_SIZE * entry_bytes);
+    const uint32_t tbytes = entry_bytes == 4u ? HJD_LUT_SIZE_S * 4u : HJD_LUT_SIZE * 2u; // bytes of one primary table
+    const uint32_t dc = ((slot_pack >> (comp * 8u)) & 7u) * tbytes;
+    const uint32_t ac = ((slot_pack >> (comp * 8u + 4u)) & 7u) * tbytes;
     return dc | (ac << 16);
 }
 
@@ -206,16 +208,16 @@ __device__ __forceinline__ void sync_core(const EntropyLds &L, const uint32_t *_
         // [0] this symbol, [1] this symbol and the next as one step (HjdTableSet::lut_s).  The pair is taken while the first
         // symbol cannot end the block (an AC advance is at most 16) and the second still starts inside the window (a step
         // is at most 31 bits): the states passed on are then exactly those of the symbol-by-symbol walk of the final pass.
-        const uint32_t ep = *reinterpret_cast<const uint32_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 2));
+        const uint32_t ep = *reinterpret_cast<const uint32_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS_S)) << 2));
         const uint32_t e1 = ep & 0xFFFFu, e2 = ep >> 16;
         // restart streams: only while the next marker is more than a step (31 bits) plus the 8 bits of the rules' look-ahead
         // away, so that no marker rule could have fired at the boundary the pair steps over
         uint32_t e = (z < 48u && p < pair_lim && (!RESTART || p + 40u < mnext)) ? e2 : e1;
         if ((e & 31u) == 0u) {
-            // code longer than HJD_LUT_BITS: second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
+            // code longer than HJD_LUT_BITS_S: second-level table on the next HJD_SEC_BITS_S bits (IsInHuffmanCodes,
             // loadjpg.cpp:335-392, for the lengths the primary table cannot hold); 0 = no such code
             const uint32_t sub = e >> 5;
-            e = sub ? L.sec[(sub - 1u) * HJD_SEC_SIZE + ((win >> 16) & (HJD_SEC_SIZE - 1u))] : 0u;
+            e = sub ? L.sec[(sub - 1u) * HJD_SEC_SIZE_S + ((win >> 16) & (HJD_SEC_SIZE_S - 1u))] : 0u;
             if ((e & 31u) == 0u) e = 16u; // skip 16 bits: any progress will do, the final pass flags it
         }
         // e = (length + value bits) | advance << 5 | records << 14
@@ -569,7 +571,7 @@ __device__ __forceinline__ void sync_window(SyncChain (&ch)[NC], const uint32_t 
         for (int c = 0; c < NC; c++) {
             win[c] = __builtin_amdgcn_alignbit(ch[c].hi, ch[c].lo, ch[c].sh);
             const uint32_t tb = ch[c].z == 0u ? ch[c].dcb : ch[c].acb;
-            w2[c] = lds_load<uint32_t>(tb + ((win[c] >> (32 - HJD_LUT_BITS)) << 2)); // [0] | [1] << 16
+            w2[c] = lds_load<uint32_t>(tb + ((win[c] >> (32 - HJD_LUT_BITS_S)) << 2)); // [0] | [1] << 16
             nw[c] = lds_load<uint32_t>(ch[c].nxa);
             mt[c] = lds_load<uint4>(ch[c].mi);
         }
@@ -590,7 +592,7 @@ __device__ __forceinline__ void sync_window(SyncChain (&ch)[NC], const uint32_t 
             for (int c = 0; c < NC; c++)
                 if ((e[c] & 31u) == 0u) {
                     const uint32_t sub = e[c] >> 5;
-                    e[c] = sub ? lds_load<uint16_t>(sec_addr + (((sub - 1u) * HJD_SEC_SIZE + ((win[c] >> 16) & (HJD_SEC_SIZE - 1u))) << 1)) : 0u;
+                    e[c] = sub ? lds_load<uint16_t>(sec_addr + (((sub - 1u) * HJD_SEC_SIZE_S + ((win[c] >> 16) & (HJD_SEC_SIZE_S - 1u))) << 1)) : 0u;
                     if ((e[c] & 31u) == 0u) e[c] = 16u; // skip 16 bits: any progress will do, the final pass flags it
                 }
         }
@@ -631,12 +633,12 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
 {
     SyncChain &c = ch[0];
     const uint32_t plim = pend[0] > 32u ? pend[0] - 32u : 0u;
-    const uint32_t secm = sec_addr - 2u * HJD_SEC_SIZE; // second-level table `sub` (1-based) starts at sec_addr + (sub - 1) * 2 * HJD_SEC_SIZE
+    const uint32_t secm = sec_addr - 2u * HJD_SEC_SIZE_S; // second-level table `sub` (1-based) starts at sec_addr + (sub - 1) * 2 * HJD_SEC_SIZE_S
     uint32_t tb = c.z == 0u ? c.dcb : c.acb;            // table of the next symbol: carried from step to step
     uint32_t win, a, w, nw, t;
     uint32_t e = 0u, tot = 0u;                          // the previous step's entry and length: its counts are added a step late
     unsigned long long act, pm, sv, bm = 0ull;
-    static_assert(HJD_LUT_BITS == 11 && HJD_SEC_BITS == 5, "field positions below");
+    static_assert(HJD_LUT_BITS_S >= 8 && HJD_LUT_BITS_S <= 12 && HJD_SEC_BITS_S == 16 - HJD_LUT_BITS_S, "field positions below: the %[lb] / %[lw] / %[sw] immediates");
     asm volatile(
         // One taken branch costs a wave as much as four instructions (tools/lat_probe.hip: 30 cycles against 8), so the loop is laid
         // out with a single one per step: its back edge is the test for the window's end, and the second-level look-up (0.2 % of
@@ -672,7 +674,7 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         "v_cndmask_b32_e64 %[acb], %[acb], v121, %[bm]\n"
         "1:\n\t"                                             // ---- next look-up
         "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"   // the next 32 bits
-        "v_bfe_u32 %[a], %[win], 21, 11\n\t"
+        "v_bfe_u32 %[a], %[win], %[lb], %[lw]\n\t"       // the next HJD_LUT_BITS_S bits
         "v_lshl_add_u32 %[a], %[a], 2, %[tb]\n\t"
         "ds_read_b32 %[w], %[a]\n\t"                       // [0] | [1] << 16
         "ds_read_b32 %[nw], %[nxa]\n\t"                    // next stream word
@@ -691,8 +693,8 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         "4:\n\t"                                             // ---- second-level table on the next HJD_SEC_BITS bits
         "s_and_saveexec_b64 %[sv], %[pm]\n\t"
         "v_bfe_u32 %[t], %[e], 5, 11\n\t"                  // 1 + table index, 0 = no code has this prefix
-        "v_bfe_u32 %[a], %[win], 16, 5\n\t"
-        "v_lshl_add_u32 %[a], %[t], 5, %[a]\n\t"
+        "v_bfe_u32 %[a], %[win], 16, %[sw]\n\t"
+        "v_lshl_add_u32 %[a], %[t], %[sw], %[a]\n\t"
         "v_lshl_add_u32 %[a], %[a], 1, %[secm]\n\t"
         "ds_read_u16 %[a], %[a]\n\t"
         "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
@@ -708,7 +710,7 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [tb] "+v"(tb),
           [acb] "+v"(c.acb), [mi] "+v"(c.mi), [nblk] "+v"(c.nblk), [nrec] "+v"(c.nrec), [e] "+v"(e), [tot] "+v"(tot), [bm] "+s"(bm),
           [win] "=&v"(win), [a] "=&v"(a), [w] "=&v"(w), [t] "=&v"(t), [nw] "=&v"(nw), [act] "=&s"(act), [pm] "=&s"(pm), [sv] "=&s"(sv)
-        : [pend] "v"(pend[0]), [plim] "v"(plim), [secm] "v"(secm)
+        : [pend] "v"(pend[0]), [plim] "v"(plim), [secm] "v"(secm), [lb] "n"(32 - HJD_LUT_BITS_S), [lw] "n"(HJD_LUT_BITS_S), [sw] "n"(HJD_SEC_BITS_S)
         : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
 }
 
@@ -769,25 +771,92 @@ __device__ __forceinline__ void decode_windows(const RowEnv &E, const bool (&liv
         }
     }
     if (im.restart) {
+        // Restart streams (round 5): the stretches of a window that no marker rule can reach — everything more than 39 bits before
+        // the next marker: a step is at most 31 bits and the rules look 8 bits ahead — go through the hand-written loop like any
+        // other stream; only within reach of a marker does a lane run the loop that knows the reference's rules (sync_core<true>,
+        // loadjpg.cpp:535-550, :631-640).  The two alternate until every lane has reached its window's end: one marker per MCU row
+        // is one rule phase in ten windows, one per MCU a rule phase or two per window.  (Rounds 3-4 ran the C++ loops for the
+        // whole window of every restart stream: 64 x 1080p with DRI 120 138 against 182 Gpixel/s without.)
+        RestartCtx rc[NC];
+        uint32_t mnext[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
+            rc[c] = {P.mpos + im.mark_off, E.nmark, 0u, im.ri_blocks, 0u, im.conformant};
+            mnext[c] = 0xFFFFFFFFu;
             if (!go[c]) continue;
-            const uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
-            RestartCtx rc = {P.mpos + im.mark_off, E.nmark, 0u, im.ri_blocks, 0u, im.conformant};
             if (mk[c] == 0xFFFFFFFFu) {
-                uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+                uint32_t lo = 0, hi = rc[c].nmark; // first marker past the state's position
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (rc.mpos[mid] <= p[c]) lo = mid + 1;
+                    if (rc[c].mpos[mid] <= p[c]) lo = mid + 1;
                     else hi = mid;
                 }
                 mk[c] = lo;
             }
-            rc.mk = min(mk[c], rc.nmark); // sync_span moves it past p
-            const uint32_t pair_lim = pend[c] > 32u ? pend[c] - 32u : 0u;
-            sync_span<true>(E.L, col, bit0[c], E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p[c], z[c], m[c], pend[c], pair_lim, nblk[c], nrec[c], rc);
-            mk[c] = rc.mk;
+            rc[c].mk = min(mk[c], rc[c].nmark);
         }
+        for (;;) {
+            bool plain[NC], anyplain = false, anyleft = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                plain[c] = false;
+                if (go[c] && p[c] < pend[c]) {
+                    while (rc[c].mk < rc[c].nmark && rc[c].mpos[rc[c].mk] <= p[c]) rc[c].mk++;
+                    mnext[c] = rc[c].mk < rc[c].nmark ? rc[c].mpos[rc[c].mk] : 0xFFFFFFFFu;
+                    plain[c] = p[c] + 40u <= mnext[c];
+                    anyleft = true;
+                }
+                anyplain = anyplain || plain[c];
+            }
+            if (!__any(anyleft)) break;
+            if (__any(anyplain)) {
+                SyncChain ch[NC];
+                uint32_t prel[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const uint32_t col = lds_addr(E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane);
+                    const uint32_t rel = plain[c] ? p[c] - bit0[c] : 0u;
+                    const uint4 me = lds_load<uint4>(E.mt4_addr + (plain[c] ? m[c] : 0u) * 16u);
+                    ch[c].p = rel;
+                    ch[c].z = plain[c] ? z[c] : 0u;
+                    ch[c].dcb = me.x;
+                    ch[c].acb = me.y;
+                    ch[c].mi = me.z;
+                    ch[c].nblk = 0u;
+                    ch[c].nrec = 0u;
+                    const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+                    const uint32_t a = lds_load<uint32_t>(col + k0 * 256u), b = lds_load<uint32_t>(col + k0 * 256u + 256u);
+                    ch[c].hi = a;
+                    ch[c].lo = o0 ? b : a;
+                    ch[c].nxa = col + (k0 + (o0 ? 2u : 1u)) * 256u;
+                    ch[c].sh = (32u - o0) & 31u;
+                    // up to 39 bits before the marker, or the window's end (two-symbol steps stop 32 bits before either)
+                    prel[c] = plain[c] ? min(pend[c], mnext[c] - 39u) - bit0[c] : 0u;
+                }
+                sync_window<NC>(ch, prel, E.sec_addr);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (plain[c]) {
+                        p[c] = bit0[c] + ch[c].p;
+                        z[c] = ch[c].z;
+                        m[c] = lds_load<uint4>(ch[c].mi).w;
+                        nblk[c] += ch[c].nblk;
+                        nrec[c] += ch[c].nrec;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (!(go[c] && p[c] < pend[c])) continue;
+                const uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
+                const uint32_t pair_lim = pend[c] > 32u ? pend[c] - 32u : 0u;
+                // runs while a marker is within reach (p + 40 > the next marker's position) and returns at the first step past that
+                sync_core<true>(E.L, col, bit0[c], E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p[c], z[c], m[c], pend[c], pair_lim, nblk[c], nrec[c], rc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (go[c]) mk[c] = rc[c].mk;
         return;
     }
     SyncChain ch[NC];

@@ -248,103 +248,7 @@ struct hjd_batch {
     int tev_cap = 0;
 };
 
-// ---- Huffman table construction (GenHuffCodes / BuildHuffmanTable, openjpg.cpp:48-98) ----------
-
-// Fills primary table `ti` of the set from one DHT payload; long codes go to secondary tables.
-// Returns false when the set runs out of secondary tables.
-static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is_dc)
-{
-    memset(ts.lut[ti], 0, sizeof(ts.lut[ti]));
-    memset(ts.lut_s[ti], 0, sizeof(ts.lut_s[ti]));
-    unsigned code = 0, idx = 0;
-    for (int k = 1; k <= 16; k++) {
-        for (unsigned j = 0; j < h.bits[k]; j++, idx++, code++) {
-            const unsigned sym = h.vals[idx];
-            unsigned s, adv;
-            if (is_dc) { // DC symbol = number of extra bits (loadjpg.cpp:616)
-                s = sym & 15;
-                adv = 1;
-            } else { // AC run/size (loadjpg.cpp:768-808)
-                s = sym & 15;
-                const unsigned r = sym >> 4;
-                if (s) adv = r + 1;
-                else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
-            }
-            const uint16_t e = (uint16_t)(k | (s << 5) | (adv << 9));
-            const uint16_t es = (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 14 : 0u)); // synchronisation form
-            if (k <= HJD_LUT_BITS) {
-                const unsigned lo = code << (HJD_LUT_BITS - k), cnt = 1u << (HJD_LUT_BITS - k);
-                for (unsigned q = 0; q < cnt; q++) {
-                    ts.lut[ti][lo + q] = e;
-                    ts.lut_s[ti][lo + q][0] = ts.lut_s[ti][lo + q][1] = es;
-                }
-            } else {
-                const unsigned prefix = code >> (k - HJD_LUT_BITS);
-                uint16_t &pe = ts.lut[ti][prefix];
-                if (pe == 0) {
-                    if (ts.nsec >= HJD_MAX_SEC) return false;
-                    memset(ts.sec[ts.nsec], 0, sizeof(ts.sec[0]));
-                    memset(ts.sec_s[ts.nsec], 0, sizeof(ts.sec_s[0]));
-                    pe = (uint16_t)((ts.nsec + 1) << 5);
-                    ts.lut_s[ti][prefix][0] = ts.lut_s[ti][prefix][1] = pe;
-                    ts.nsec++;
-                }
-                const unsigned si = (pe >> 5) - 1;
-                const unsigned rem = code & ((1u << (k - HJD_LUT_BITS)) - 1);
-                const unsigned sbits = HJD_SEC_BITS - (k - HJD_LUT_BITS);
-                for (unsigned q = 0; q < (1u << sbits); q++) {
-                    ts.sec[si][(rem << sbits) + q] = e;
-                    ts.sec_s[si][(rem << sbits) + q] = es;
-                }
-            }
-        }
-        code <<= 1;
-    }
-    if (!is_dc) {
-        // two AC symbols in one step of the synchronisation pass (HjdTableSet::lut_s): the bits after the first symbol
-        // (code + value bits) that the window still holds are looked up again, left-aligned and zero-padded; the pair
-        // exists if that finds a code no longer than the bits that are really there
-        for (unsigned i = 0; i < HJD_LUT_SIZE; i++) {
-            const unsigned e1 = ts.lut_s[ti][i][0];
-            const unsigned tot1 = e1 & 31u, adv1 = (e1 >> 5) & 127u;
-            if (tot1 == 0 || tot1 >= HJD_LUT_BITS || adv1 == 0 || adv1 > 16) continue; // long code, no room, invalid symbol, EOB
-            const unsigned rem = HJD_LUT_BITS - tot1;
-            const unsigned i2 = (i << tot1) & (HJD_LUT_SIZE - 1u);
-            const unsigned w2 = ts.lut[ti][i2];
-            const unsigned l2 = w2 & 31u, s2 = (w2 >> 5) & 15u, adv2 = w2 >> 9;
-            if (l2 == 0 || l2 > rem || adv2 == 0) continue;
-            const unsigned tot = tot1 + l2 + s2, rec = (e1 >> 14) + (s2 ? 1u : 0u);
-            if (tot > 31u) continue;
-            ts.lut_s[ti][i][1] = (uint16_t)(tot | ((adv1 + adv2) << 5) | (rec << 14));
-        }
-    }
-    return true;
-}
-
-// One table set per distinct (DC,AC) x (Y,Cb,Cr) configuration; identical payloads share a table.
-static bool build_tabset(HjdTableSet &ts, const hjd_jpeg_data &j)
-{
-    memset(&ts, 0, sizeof(ts));
-    const hjd_huff_spec *specs[HJD_SLOTS];
-    for (int c = 1; c <= 3; c++) {
-        specs[(c - 1) * 2 + 0] = &j.htdc[j.dc_table_index[c]];
-        specs[(c - 1) * 2 + 1] = &j.htac[j.ac_table_index[c]];
-    }
-    for (int sl = 0; sl < HJD_SLOTS; sl++) {
-        int ti = -1;
-        for (int q = 0; q < sl; q++)
-            if ((q & 1) == (sl & 1) && !memcmp(specs[q]->bits, specs[sl]->bits, 17) && !memcmp(specs[q]->vals, specs[sl]->vals, 256)) {
-                ti = (int)((ts.slot_pack >> (q * 4)) & 7);
-                break;
-            }
-        if (ti < 0) {
-            ti = (int)ts.nlut++;
-            if (!build_table(ts, ti, *specs[sl], (sl & 1) == 0)) return false;
-        }
-        ts.slot_pack |= (uint32_t)ti << (sl * 4);
-    }
-    return true;
-}
+// (Huffman table construction: hjd_build_tabset, host/hjd_host.cpp — plain C++, covered by `make sanitize`)
 
 static std::string tabset_key(const hjd_jpeg_data &j)
 {
@@ -596,7 +500,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     std::map<std::string, uint32_t> tab_index;
     std::vector<HjdTableSet> tabs;
     size_t raw_cur = 0, us_cur = 0, blk_cur = 0, rec_cur = 0, out_cur = 0;
-    uint32_t max_nlut = 1, max_nsec = 0;
+    uint32_t max_nlut = 1, max_nsec = 0, max_nsec_s = 0;
     const uint32_t Q = HJD_SYNC_WG - K; // owned subsequences per synchronisation workgroup
 
     for (int i = 0; i < b->n; i++) {
@@ -626,12 +530,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         auto it = tab_index.find(key);
         if (it == tab_index.end()) {
             HjdTableSet ts;
-            if (!build_tabset(ts, j)) { // more long-code prefixes than the secondary tables hold
+            if (!hjd_build_tabset(ts, j)) { // more long-code prefixes than the secondary tables hold
                 b->parse_status[i] = HJD_ERR_UNSUPPORTED;
                 continue;
             }
             max_nlut = ts.nlut > max_nlut ? ts.nlut : max_nlut;
             max_nsec = ts.nsec > max_nsec ? ts.nsec : max_nsec;
+            max_nsec_s = ts.nsec_s > max_nsec_s ? ts.nsec_s : max_nsec_s;
             it = tab_index.emplace(key, (uint32_t)tabs.size()).first;
             tabs.push_back(ts);
         }
@@ -806,8 +711,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.write_windows = wwn;
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
         P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
-        P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE; // two u16 entries per index
-        P.lds_state_word_s = (P.lds_sec_word_s + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
+        P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE_S; // two u16 entries per index
+        P.lds_state_word_s = (P.lds_sec_word_s + max_nsec_s * (HJD_SEC_SIZE_S / 2) + 3) & ~3u;
         // k_sync: five word arrays + the u8 marks + 96 words (scratch, block tables), then one staging window per slot (the first
         // 2 x HJD_SYNC_WG words of which double as the work list)
         P.lds_bytes_sync = (P.lds_state_word_s + 5 * HJD_SYNC_WG + HJD_SYNC_WG / 4 + 96 + (HJD_SYNC_WG / 64) * (wpp + 2) * 64) * 4;

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/hjd.h"
+#include "../csrc/hjd_device.h"
 #include "hjd_internal.h"
 
 static thread_local int t_last_status = HJD_OK;
@@ -212,6 +213,127 @@ walked:
     o->vfactor = (uint8_t)vf;
     return HJD_OK;
 }
+
+// ---- Huffman table construction (GenHuffCodes / BuildHuffmanTable, openjpg.cpp:48-98) ----------
+
+// Fills primary table `ti` of the set from one DHT payload; long codes go to secondary tables.
+// Returns false when the set runs out of secondary tables.
+static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is_dc)
+{
+    memset(ts.lut[ti], 0, sizeof(ts.lut[ti]));
+    memset(ts.lut_s[ti], 0, sizeof(ts.lut_s[ti]));
+    // The two forms are built alike, each on its own index width (HJD_LUT_BITS / HJD_LUT_BITS_S: the prefixes that need a
+    // second-level table differ with the width): put(form, index, entry), sec_new(form) -> index of a fresh second-level table or -1.
+    auto fill = [&](const unsigned bits, const bool sync_form) -> bool {
+        const unsigned sec_bits = 16 - bits;
+        unsigned code = 0, idx = 0;
+        for (int k = 1; k <= 16; k++) {
+            for (unsigned j = 0; j < h.bits[k]; j++, idx++, code++) {
+                const unsigned sym = h.vals[idx];
+                unsigned s, adv;
+                if (is_dc) { // DC symbol = number of extra bits (loadjpg.cpp:616)
+                    s = sym & 15;
+                    adv = 1;
+                } else { // AC run/size (loadjpg.cpp:768-808)
+                    s = sym & 15;
+                    const unsigned r = sym >> 4;
+                    if (s) adv = r + 1;
+                    else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
+                }
+                const uint16_t e = sync_form ? (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 14 : 0u)) // synchronisation form
+                                             : (uint16_t)(k | (s << 5) | (adv << 9));
+                if ((unsigned)k <= bits) {
+                    const unsigned lo = code << (bits - k), cnt = 1u << (bits - k);
+                    for (unsigned q = 0; q < cnt; q++) {
+                        if (sync_form) ts.lut_s[ti][lo + q][0] = ts.lut_s[ti][lo + q][1] = e;
+                        else ts.lut[ti][lo + q] = e;
+                    }
+                } else {
+                    const unsigned prefix = code >> (k - bits);
+                    uint16_t pe = sync_form ? ts.lut_s[ti][prefix][0] : ts.lut[ti][prefix];
+                    if (pe == 0) {
+                        uint32_t &nsec = sync_form ? ts.nsec_s : ts.nsec;
+                        if (nsec >= HJD_MAX_SEC) return false;
+                        if (sync_form) memset(ts.sec_s[nsec], 0, sizeof(ts.sec_s[0]));
+                        else memset(ts.sec[nsec], 0, sizeof(ts.sec[0]));
+                        pe = (uint16_t)((nsec + 1) << 5);
+                        if (sync_form) ts.lut_s[ti][prefix][0] = ts.lut_s[ti][prefix][1] = pe;
+                        else ts.lut[ti][prefix] = pe;
+                        nsec++;
+                    }
+                    const unsigned si = (pe >> 5) - 1;
+                    const unsigned rem = code & ((1u << (k - bits)) - 1);
+                    const unsigned sbits = sec_bits - (k - bits);
+                    for (unsigned q = 0; q < (1u << sbits); q++) {
+                        if (sync_form) ts.sec_s[si][(rem << sbits) + q] = e;
+                        else ts.sec[si][(rem << sbits) + q] = e;
+                    }
+                }
+            }
+            code <<= 1;
+        }
+        return true;
+    };
+    if (!fill(HJD_LUT_BITS, false) || !fill(HJD_LUT_BITS_S, true)) return false;
+    if (!is_dc) {
+        // two AC symbols in one step of the synchronisation pass (HjdTableSet::lut_s): the bits after the first symbol
+        // (code + value bits) that the window still holds are looked up again, left-aligned and zero-padded; the pair
+        // exists if that finds a code no longer than the bits that are really there
+        for (unsigned i = 0; i < HJD_LUT_SIZE_S; i++) {
+            const unsigned e1 = ts.lut_s[ti][i][0];
+            const unsigned tot1 = e1 & 31u, adv1 = (e1 >> 5) & 127u;
+            if (tot1 == 0 || tot1 >= HJD_LUT_BITS_S || adv1 == 0 || adv1 > 16) continue; // long code, no room, invalid symbol, EOB
+            const unsigned rem = HJD_LUT_BITS_S - tot1;
+            const unsigned i2 = (i << tot1) & (HJD_LUT_SIZE_S - 1u);
+            const unsigned w2 = ts.lut_s[ti][i2][0]; // (the second symbol's one-symbol entry: total bits | advance << 5 | records << 14)
+            const unsigned t2 = w2 & 31u, adv2 = (w2 >> 5) & 127u;
+            if (t2 == 0 || adv2 == 0) continue;
+            // its code must lie wholly inside the bits that are really there: code length = total - value bits, from the final-pass
+            // form of the same symbol where the widths agree; here recovered from the canonical code itself
+            unsigned l2 = 0;
+            {   // length of the code that the rem bits of i2's top start with
+                unsigned code = 0, first = 0;
+                const unsigned top = i2 << (16 - HJD_LUT_BITS_S); // 16-bit left-aligned view
+                for (int k = 1; k <= 16 && !l2; k++) {
+                    code = top >> (16 - k);
+                    if (code >= first && code < first + h.bits[k]) l2 = (unsigned)k;
+                    first = (first + h.bits[k]) << 1;
+                }
+            }
+            if (l2 == 0 || l2 > rem) continue;
+            const unsigned tot = tot1 + t2, rec = (e1 >> 14) + (w2 >> 14);
+            if (tot > 31u) continue;
+            ts.lut_s[ti][i][1] = (uint16_t)(tot | ((adv1 + adv2) << 5) | (rec << 14));
+        }
+    }
+    return true;
+}
+
+// One table set per distinct (DC,AC) x (Y,Cb,Cr) configuration; identical payloads share a table.
+bool hjd_build_tabset(HjdTableSet &ts, const hjd_jpeg_data &j)
+{
+    memset(&ts, 0, sizeof(ts));
+    const hjd_huff_spec *specs[HJD_SLOTS];
+    for (int c = 1; c <= 3; c++) {
+        specs[(c - 1) * 2 + 0] = &j.htdc[j.dc_table_index[c]];
+        specs[(c - 1) * 2 + 1] = &j.htac[j.ac_table_index[c]];
+    }
+    for (int sl = 0; sl < HJD_SLOTS; sl++) {
+        int ti = -1;
+        for (int q = 0; q < sl; q++)
+            if ((q & 1) == (sl & 1) && !memcmp(specs[q]->bits, specs[sl]->bits, 17) && !memcmp(specs[q]->vals, specs[sl]->vals, 256)) {
+                ti = (int)((ts.slot_pack >> (q * 4)) & 7);
+                break;
+            }
+        if (ti < 0) {
+            ti = (int)ts.nlut++;
+            if (!build_table(ts, ti, *specs[sl], (sl & 1) == 0)) return false;
+        }
+        ts.slot_pack |= (uint32_t)ti << (sl * 4);
+    }
+    return true;
+}
+
 
 // ---- sizes / BMP (WriteBMP24, openjpg.cpp:504-570) ------------------------------------------------
 

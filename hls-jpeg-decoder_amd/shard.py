@@ -83,3 +83,19 @@ def agree(elapsed_s, units, device=None):
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def gather_per_rank(rank, device_index, elapsed_s, steps, device=None):
+    """Every rank's own step time, for rank 0's JSON line: [{"rank", "device", "ms_per_step"}, ...] in rank order.  MAX-of-time
+    (agree) hides which rank was the slow one; a straggler shows here.  One all-gather of three numbers, outside the timed region."""
+    import torch
+    import torch.distributed as dist
+    mine = [float(rank), float(device_index), float(elapsed_s) / max(1, int(steps)) * 1e3]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        rows = [mine]
+    else:
+        t = torch.tensor(mine, dtype=torch.float64, device=device)
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        rows = [[float(x) for x in o.tolist()] for o in out]
+    return [{"rank": int(r[0]), "device": int(r[1]), "ms_per_step": round(r[2], 4)} for r in rows]

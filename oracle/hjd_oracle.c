@@ -22,7 +22,7 @@ static const uint8_t ZZ[64] = {
 
 /* COS[x][u] = cosf(fl((2x+1)*u*3.14f)/16) as glibc 2.35 evaluates it on x86-64
  * (loadjpg.cpp:108,120).  Hard-coded: entry [6][7] is libm-specific (SURVEY
- * App. B); tools/gen_costable.c regenerates and compares it. */
+ * App. B); tools/gen_costable.c regenerates it from the reference's expression with the local libm and compares. */
 static const float COS[8][8] = {
     {0x1p+0f, 0x1.f62c08p-1f, 0x1.d910b8p-1f, 0x1.a9cc2p-1f, 0x1.6a2ecap-1f, 0x1.1ca9eep-1f, 0x1.886ecap-2f, 0x1.90f1bep-3f},
     {0x1p+0f, 0x1.a9cc2p-1f, 0x1.886ecap-2f, -0x1.8dbedp-3f, -0x1.699b2p-1f, -0x1.f6032cp-1f, -0x1.d9606ap-1f, -0x1.1d5756p-1f},

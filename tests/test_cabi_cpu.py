@@ -171,3 +171,13 @@ def test_reference_main_links_against_the_library(hjd, tmp_path):
                         "-L" + os.path.dirname(hjd.LIB_PATH), "-lhjd", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(exe)
+
+
+def test_sanitizer_build_of_the_host_side():
+    """`make sanitize` (shortened): the header walk, the validation of parsed and caller-filled structs and the Huffman table builder,
+    compiled with AddressSanitizer + UBSan, fed 40 000 mutated headers of seven fixtures (tests/fuzz_header.cpp).  The reference has
+    no tests and no sanitizer runs; GPU sanitizers are not available on the pool, so this is the host side only."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "sanitize", "FUZZ_ITERS=40000"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "clean" in r.stdout and "40000 inputs" in r.stdout, r.stdout[-500:]

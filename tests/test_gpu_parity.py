@@ -920,6 +920,7 @@ def test_bench_launches_its_own_ranks(tmp_path, world):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == world and line["config"]["images_per_gpu"] == 8 and line["parity"] == "ok"
+    assert [p["rank"] for p in line["per_rank"]] == list(range(world)) and all(0 < p["ms_per_step"] <= line["ms_per_step"] + 1e-3 for p in line["per_rank"])
     px = 8 * world * 1920 * 1080
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - px) / px < 0.02
 

@@ -10,6 +10,8 @@ import pytest
 
 import hjdtools as T
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _masked_bmp(rgb):
     h, w, _ = rgb.shape
@@ -83,13 +85,53 @@ def test_idct_zero_skip_equals_full_terms():
         assert (a == b).all()
 
 
-def test_cos_table_matches_runtime_libm_note():
-    """The hard-coded table is the contract; this records whether the local libm
-    still reproduces it and fails only if the TABLE itself was edited."""
-    t = np.ctypeslib.as_array(T.oracle_lib().hjo_cos_table(), shape=(64,)).copy().reshape(8, 8)
-    assert t[6, 7] == np.float32(float.fromhex("0x1.1895aep-1"))
-    assert t[0, 0] == 1.0 and t[3, 2] == np.float32(float.fromhex("-0x1.d8c0bap-1"))
-    assert hashlib.sha256(t.tobytes()).hexdigest()[:16] == hashlib.sha256(t.astype(np.float32).tobytes()).hexdigest()[:16]
+APP_B = """
+0x1p+0  0x1.f62c08p-1  0x1.d910b8p-1  0x1.a9cc2p-1   0x1.6a2ecap-1  0x1.1ca9eep-1  0x1.886ecap-2  0x1.90f1bep-3
+0x1p+0  0x1.a9cc2p-1   0x1.886ecap-2 -0x1.8dbedp-3  -0x1.699b2p-1  -0x1.f6032cp-1 -0x1.d9606ap-1 -0x1.1d5756p-1
+0x1p+0  0x1.1ca9eep-1 -0x1.86ed1p-2  -0x1.f6032cp-1 -0x1.6ac236p-1  0x1.8a8b92p-3  0x1.d8706ep-1  0x1.aab36ap-1
+0x1p+0  0x1.90f1bep-3 -0x1.d8c0bap-1 -0x1.1d5756p-1  0x1.690742p-1  0x1.aab36ap-1 -0x1.83e8d8p-2 -0x1.f6a4aep-1
+0x1p+0 -0x1.8dbedp-3  -0x1.d9606ap-1  0x1.1b4e94p-1  0x1.6b556cp-1 -0x1.a86f2p-1  -0x1.8cf256p-2  0x1.f5869ep-1
+0x1p+0 -0x1.1bfc56p-1 -0x1.89f044p-2  0x1.f67ccap-1 -0x1.68731cp-1 -0x1.9a88c4p-3  0x1.da4da2p-1 -0x1.a7851ep-1
+0x1p+0 -0x1.a9581p-1   0x1.856b06p-2  0x1.9756cp-3  -0x1.6be866p-1  0x1.f6cc3cp-1 -0x1.d77dbp-1   0x1.1895aep-1
+0x1p+0 -0x1.f6032cp-1  0x1.d8706ep-1 -0x1.a86f2p-1   0x1.67dec4p-1 -0x1.19442cp-1  0x1.7f609p-2  -0x1.7a87f6p-3
+"""  # SURVEY.md App. B: what the reference's x86-64 / glibc 2.35 build evaluates, row = x (or y), column = u (or v)
+
+
+def test_cos_table_is_appendix_b_everywhere():
+    """All 64 entries, in every place that holds them: the oracle's table and the table the HIP kernel is compiled with
+    (csrc/hjd_pixels.hip: c_cos) equal SURVEY App. B bit for bit."""
+    import re
+    want = np.array([float.fromhex(x) for x in APP_B.split()], np.float32)
+    assert want.size == 64 and want[6 * 8 + 7] == np.float32(float.fromhex("0x1.1895aep-1"))   # the libm-specific entry, not 0x1.1895b0p-1
+    t = np.ctypeslib.as_array(T.oracle_lib().hjo_cos_table(), shape=(64,)).copy()
+    assert t.dtype == np.float32 and t.tobytes() == want.tobytes()
+    src = open(os.path.join(ROOT, "hls-jpeg-decoder_amd", "csrc", "hjd_pixels.hip")).read()
+    body = src[src.index("__constant__ float c_cos[64] = {") + len("__constant__ float c_cos[64] = {"):]
+    body = body[:body.index("};")]
+    dev = np.array([float.fromhex(x.rstrip("f")) for x in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+f", body)], np.float32)
+    assert dev.size == 64 and dev.tobytes() == want.tobytes()
+
+
+def test_cos_table_is_what_the_reference_expression_gives_on_this_libm():
+    """The reference computes cosf(((2*x+1) * u * PI) / 16) with PI = 3.14f at run time (loadjpg.cpp:108, :120).  Where the
+    local libm is the one the reference hashes were produced on (glibc 2.35: the build container and the GPU box image) all 64
+    values must come out as the table; on another libm the comparison is skipped with a message — the table, not the libm, is
+    the contract.  tools/gen_costable.c is the same check as a C program."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.cosf.restype = ctypes.c_float
+    libm.cosf.argtypes = [ctypes.c_float]
+    want = np.array([float.fromhex(x) for x in APP_B.split()], np.float32).reshape(8, 8)
+    f = np.float32
+    got = np.empty((8, 8), np.float32)
+    for x in range(8):
+        for u in range(8):
+            arg = f(f(f((2 * x + 1) * u) * f(3.14)) / f(16))   # int * int, then * float, then / 16: one rounding per operation
+            got[x, u] = libm.cosf(float(arg))
+    diff = [(x, u) for x in range(8) for u in range(8) if got[x, u].tobytes() != want[x, u].tobytes()]
+    if diff:
+        pytest.skip("this libm's cosf differs from glibc 2.35's at %s: the hard-coded table stays the contract" % diff)
 
 
 def test_bmp_header_bytes(golden):

@@ -120,6 +120,9 @@ def test_eight_rank_rehearsal_of_config4_plumbing():
     # SUM over the 8 ranks of their shards' pixels, MAX over the ranks of their (made-up) clocks: rank 7's 8 ms per step
     assert abs(line["ms_per_step"] - 8.0) < 1e-6
     assert abs(line["value"] - 8192 * 1920 * 1080 / 8.0e-3 / 1e6) < 1.0
+    # every rank's own step time is in the line (the value uses the MAX: without this a straggler is invisible)
+    assert [p["rank"] for p in line["per_rank"]] == list(range(8))
+    assert all(abs(p["ms_per_step"] - (p["rank"] + 1)) < 1e-6 for p in line["per_rank"])
 
 
 def test_a_dead_rank_ends_the_job_within_seconds():
