@@ -43,11 +43,11 @@ class JpegData(ctypes.Structure):
 
 class LayoutInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in (
-        "subseq_bits", "sync_overlap", "phase_words", "sync_wg", "write_wg", "group_mcus", "unstuff_chunk", "rec_run",
-        "nblocks", "mcux", "mcuy", "nb", "nchunks", "nsub_cap", "nsyncwg", "nrepwg", "nwritewg", "ngroups",
+        "subseq_bits", "sync_overlap", "phase_words", "sync_wg", "write_wg", "group_mcus", "unstuff_chunk", "dc_chunk", "rec_run",
+        "nblocks", "mcux", "mcuy", "nb", "nchunks", "nsub_cap", "nsyncwg", "nrepwg", "nwritewg", "ndcchunk", "ngroups",
         "groups_per_row", "mark_cap", "rec_cap", "out_stride", "lds_bytes_sync", "lds_bytes_write", "lds_state_word", "lds_state_word_sync")] + \
-        [(n, ctypes.c_uint64) for n in ("raw_bytes", "ustream_bytes", "blk_entries", "rec_entries", "out_bytes",
-                                        "substate_entries", "wgsum_entries", "wgdc_entries", "ckpt_entries",
+        [(n, ctypes.c_uint64) for n in ("raw_bytes", "ustream_bytes", "blk_entries", "dca_entries", "rec_entries", "out_bytes",
+                                        "substate_entries", "wgsum_entries", "dcsum_entries", "ckpt_entries",
                                         "seg_cap", "seg_nodes", "seg_slab_bytes")]
 
 

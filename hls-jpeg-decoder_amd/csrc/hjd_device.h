@@ -14,16 +14,12 @@
 //              slot = u*8+v is the coefficient's place after DeZigZag + TransformArray (loadjpg.cpp:156-180), u the
 //              horizontal frequency; all ones = padding), every subsequence's run rounded up to HJD_REC_RUN
 //              records so that it is written in aligned 16-byte stores
-//   blk      : one uint2 per block: x = index of the block's first record; y = low half: the running sum (mod 2^16) of the DC
-//              differences of the block's component over the blocks whose DC symbol lies in the same final-pass workgroup, up to
-//              and including this block, high half: that workgroup's number within the image (0xFFFF: the low half is the DC
-//              value itself — the emulation kernels write it that way).  Written once and whole (8 bytes) by the final-pass
-//              workgroup that decoded the block's DC symbol; read by the back end.  One extra entry per image closes the last
-//              block's record range.  (Until round 4: the DC difference, turned into DC values by two further launches —
-//              k_dcsum / k_dcapply — through a 2-byte array dca[].)
-//   wgdc     : per final-pass workgroup (wgsum numbering) the sums of its blocks' DC differences per component, and — second half
-//              of the array, written by the image's LAST final-pass workgroup to finish — their exclusive prefix over the
-//              image's workgroups: DC prediction (loadjpg.cpp:619-667, predictors never reset :1159-1162) = base + running sum
+//   blk      : one uint2 per block: x = index of the block's first record, y = the decoded DC difference (int16 in the low half).
+//              Written once and whole (8 bytes) by the k_write lane that decoded the block's DC symbol; read by the DC prediction
+//              kernels (y) and, at the borders of its groups only, by the back end (x).  One extra entry per image closes the
+//              last block's record range.  (Until round 4: 16 bytes with the mask of the slots the block's records fill, and the DC
+//              difference a second time in a 2-byte array of its own — the back end now builds the masks from the records.)
+//   dca      : per block, the DC value after prediction (int16), written by k_dcapply
 //   wgmap    : for every kernel's workgroup numbering, workgroup -> image (one load instead of a search)
 //   mpos/mval: restart mode only — bit position (in the unstuffed stream, markers removed) and second
 //              byte of every marker found inside the scan
@@ -70,6 +66,7 @@
 #define HJD_ENT_CAP 2048u      // block entries a final-pass workgroup collects in LDS before it writes them out together
 #endif
 #define HJD_GROUP_MCUS 16      // MCUs per IDCT/colour workgroup
+#define HJD_DC_CHUNK 256       // MCUs per DC-prediction workgroup (one per thread)
 
 // Huffman decode tables of one distinct (DC/AC x 3 components) configuration.
 // Primary table: indexed by the next HJD_LUT_BITS bits.  Entry (u16):
@@ -126,6 +123,8 @@ struct HjdImage {
     uint32_t nwritewg;
     uint32_t repwg0;        // first repair workgroup (HJD_SYNC_WG subsequences each, no overlap)
     uint32_t nrepwg;
+    uint32_t dcchunk0;      // first DC-prediction chunk
+    uint32_t ndcchunk;
     uint32_t group0;        // first IDCT/colour workgroup
     uint32_t groups_per_row;
     uint32_t ngroups;
@@ -173,8 +172,6 @@ struct HjdImageState {
     uint32_t sync_iters_max;
     uint32_t nmarkers;      // restart mode: markers (FF xx, xx != 0) found inside the scan
     uint32_t emulated;      // the emulation (hjd_seq.hip) has decoded this image in this run: 1 = one lane, 2 = parallel over the resynchronisations
-    uint32_t wg_done;       // final-pass workgroups of this run that have left their DC sums (the last one adds them up: wgdc)
-    uint32_t pad_;
 };
 #define HJD_FLAG_BAD_CODE 1u      // no Huffman code matched on the true path
 #define HJD_FLAG_OVERRUN 2u       // zig-zag index ran past 63 (loadjpg.cpp:780-806)

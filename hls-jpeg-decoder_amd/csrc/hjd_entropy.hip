@@ -158,15 +158,11 @@ struct WriteCtx {
     uint32_t tag;           // block bits of a record: (block & 127) << 22
     uint32_t *ent;          // LDS: the workgroup's block entries in the making (HJD_ENT_CAP words, all ones = not written here)
     uint32_t b0, r0;        // the workgroup's first block / first record
-    uint32_t ecap;          // entries that wait in LDS: ENTCAP, or 0 when the workgroup's records would not fit the 16-bit relative index
 };
 
 // The entry of block b = (first record, DC difference), made by the lane that decoded the block's DC symbol (bfirst != ~0), when
 // the block ends or the lane's span does.  A workgroup's blocks are consecutive, so the entries wait in LDS — 4 bytes: first
-// record relative to the workgroup's first | DC difference << 16 — and leave together at the end, whole lines of them, after the
-// differences have been turned into running sums (k_write's epilogue: the DC prediction).  Blocks beyond the staging go straight out
-// (first record, DC difference) and are brought up to date in place.  W.ecap is uniform over the workgroup: ENTCAP, or 0 when the
-// workgroup's records (known before the decode, from the checkpoints) would not fit the 16-bit relative index.
+// record relative to the workgroup's first | DC difference << 16 — and leave together at the end, whole lines of them (k_write).
 // (Rounds 2-3 stored 16 bytes per block, with the mask of the slots the block's records fill, plus the DC difference once more
 // into a 2-byte array for the DC prediction kernels; every such lone store cost a 32-byte write: k_write wrote 1.8 times its
 // useful bytes.  The back end builds the masks from the records themselves — it touches every record anyway.)
@@ -174,9 +170,9 @@ template <uint32_t ENTCAP>
 __device__ __forceinline__ void write_block_entry(WriteCtx &W, uint32_t b)
 {
     if (W.bfirst != 0xFFFFFFFFu) {
-        const uint32_t idx = b - W.b0;
-        if (idx < W.ecap) W.ent[idx] = (W.bfirst - W.r0) | (W.bdc << 16);
-        else W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu); // more blocks (or records) than the staging holds: straight out
+        const uint32_t idx = b - W.b0, rel = W.bfirst - W.r0;
+        if (idx < ENTCAP && rel < 0xFFFFu) W.ent[idx] = rel | (W.bdc << 16);
+        else W.blk[b] = make_uint2(W.bfirst, W.bdc & 0xFFFFu); // more blocks or records than the staging holds: straight out
     }
     W.bfirst = 0xFFFFFFFFu;
 }
@@ -1858,6 +1854,7 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
     block_excl_scan2(blk, nrec, s_w + 16, &tot_b, &tot_r);
     blk += base_b;
     nrec += base_r;
+    (void)tot_r;
     uint32_t flags = 0;
     if (tid == 0 && (wg + 1u) * WGSZ >= nsub * nu) { // the workgroup that holds the last span
         P.st[ii].total_blocks = base_b + tot_b;
@@ -1894,9 +1891,7 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
         }
     }
 
-    const uint32_t z_start = z;
-    const uint32_t ecap = tot_r < 0xFFFFu ? ENTCAP : 0u; // every record index of the workgroup, relative to its first, fits 16 bits (0xFFFF is kept free: all ones = no entry)
-    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks, s_slot, 0xFFFFFFFFu, 0u, 0u, s_ent, base_b, base_r, ecap};
+    WriteCtx W = {s_ring + tid, P.rec + im.rec_off, im.rec_cap, P.blk + im.blk_off, im.nblocks, s_slot, 0xFFFFFFFFu, 0u, 0u, s_ent, base_b, base_r};
     W.tag = (blk & 127u) << 22; // records before the first DC symbol belong to a block begun in an earlier span
     const uint32_t nrec0 = nrec;
     const uint32_t row_bit0 = i * S;
@@ -1936,98 +1931,15 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
     // one atomic per wave
     for (int d = 32; d >= 1; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
     if (lane == 0 && flags) atomicOr(&P.st[ii].flags, flags);
-    // ---- DC prediction (round 5; until round 4 two further launches, k_dcsum / k_dcapply, and a 2-byte array of their own) ----
-    // DCT[0] = diff + previousDC per component, predictors zeroed once per image and never reset (loadjpg.cpp:619-667, :1159-1162),
-    // int16 wrap (:664-665) = a prefix sum mod 2^16 over the blocks of each component in decode order.  The workgroup's entries —
-    // blocks [base_b, base_b + tot_b], the last one in progress at the workgroup's end; those whose DC symbol lies in this workgroup —
-    // hold the differences: every lane takes a run of consecutive entries, the runs' sums are scanned over the workgroup, and the
-    // entries leave with the running sum inside the workgroup and the workgroup's number; the sums over the whole workgroups before
-    // it are added by the back end (wgdc: written by the image's last final-pass workgroup to finish, below).
-    // Which entries are this workgroup's: in LDS all ones = not written; of those that went straight out, every block that BEGINS in
-    // the workgroup — all but block base_b when the workgroup starts inside it, and block base_b + tot_b when the workgroup ends
-    // between two blocks.
-    __threadfence_block(); // the entries that went straight out are read back by other lanes of the workgroup
-    __syncthreads();       // every lane has left the decode loop: its tables' place in s_w is free
-    if (tid == 0) s_w[28] = z_start;                                                      // the workgroup's start state ...
-    if (valid && (tid == WGSZ - 1u || u + 1u == nsub * nu)) s_w[29] = mine.y & 63u;       // ... and the state at its end (its last span's checkpoint)
+    // the workgroup's block entries: blocks [base_b, base_b + tot_b] (the last one in progress at the workgroup's end), those whose DC
+    // symbol lies in this workgroup; 8 bytes each, consecutive lanes consecutive blocks
     __syncthreads();
     {
-        const uint32_t z_first = s_w[28], z_last = s_w[29];
-        const uint32_t nent = base_b < im.nblocks ? min(tot_b + 1u, im.nblocks - base_b) : 0u;
-        const uint32_t CH = (nent + WGSZ - 1u) / WGSZ, k0 = min(tid * CH, nent), k1 = min(k0 + CH, nent);
         uint2 *blk_out = P.blk + im.blk_off + base_b;
-        const uint32_t nb = im.nb, nby = im.nby;
-        auto diff_of = [&](uint32_t k, bool &own) -> uint32_t {
-            if (k < ecap) {
-                const uint32_t v = s_ent[k];
-                own = v != 0xFFFFFFFFu;
-                return (uint32_t)(int)(int16_t)(v >> 16);
-            }
-            own = (k != 0u || z_first == 0u) && (k != tot_b || z_last != 0u);
-            return own ? (uint32_t)(int)(int16_t)blk_out[k].y : 0u;
-        };
-        uint32_t sy = 0, scb = 0, scr = 0;
-        uint32_t mm = (base_b + k0) % nb;
-        for (uint32_t k = k0; k < k1; k++) {
-            bool own;
-            const uint32_t d = diff_of(k, own);
-            if (own) {
-                if (mm < nby) sy += d;
-                else if (mm == nby) scb += d;
-                else scr += d;
-            }
-            mm = mm + 1u == nb ? 0u : mm + 1u;
-        }
-        uint32_t ty, tcb, tcr;
-        block_excl_scan3(sy, scb, scr, s_w, &ty, &tcb, &tcr); // (s_w[0..23]; 28 and 29 have been read by everybody: the barrier inside comes after)
-        mm = (base_b + k0) % nb;
-        for (uint32_t k = k0; k < k1; k++) {
-            bool own;
-            const uint32_t d = diff_of(k, own);
-            if (own) {
-                uint32_t &run = mm < nby ? sy : (mm == nby ? scb : scr);
-                run += d;
-                if (k < ecap) s_ent[k] = (s_ent[k] & 0xFFFFu) | (run << 16);
-                else blk_out[k].y = (run & 0xFFFFu) | (wg << 16);
-            }
-            mm = mm + 1u == nb ? 0u : mm + 1u;
-        }
-        if (tid == 0) P.wgdc[im.wgsum0 + wg] = make_uint4(ty, tcb, tcr, 0u);
-        __syncthreads();
-        // 8 bytes each, consecutive lanes consecutive blocks
-        const uint32_t n = min(nent, ecap);
+        const uint32_t n = min(tot_b + 1u, ENTCAP);
         for (uint32_t k = tid; k < n; k += WGSZ) {
             const uint32_t v = s_ent[k];
-            if (v != 0xFFFFFFFFu) blk_out[k] = make_uint2(base_r + (v & 0xFFFFu), (v >> 16) | (wg << 16));
-        }
-    }
-    // The image's last final-pass workgroup to finish turns the workgroups' sums into their exclusive prefixes (a counter in the
-    // image's state, zeroed with it by k_unstuff_count; device-scope release / acquire around it).
-    {
-        const uint32_t nact = (nsub * nu + WGSZ - 1u) / WGSZ; // workgroups of the image that hold a span (the grid is laid out by capacity)
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_w[30] = atomicAdd(&P.st[ii].wg_done, 1u);
-        __syncthreads();
-        if (s_w[30] + 1u == nact) {
-            __threadfence();
-            const uint32_t *tot = reinterpret_cast<const uint32_t *>(P.wgdc + im.wgsum0);
-            uint4 *base = P.wgdc + P.wgdc_n + im.wgsum0;
-            const uint32_t CH = (nact + WGSZ - 1u) / WGSZ, k0 = min(tid * CH, nact), k1 = min(k0 + CH, nact);
-            uint32_t sy = 0, scb = 0, scr = 0;
-            for (uint32_t k = k0; k < k1; k++) {
-                sy += __hip_atomic_load(&tot[k * 4u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                scb += __hip_atomic_load(&tot[k * 4u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                scr += __hip_atomic_load(&tot[k * 4u + 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            uint32_t ty, tcb, tcr;
-            block_excl_scan3(sy, scb, scr, s_w, &ty, &tcb, &tcr);
-            for (uint32_t k = k0; k < k1; k++) {
-                base[k] = make_uint4(sy, scb, scr, 0u);
-                sy += __hip_atomic_load(&tot[k * 4u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                scb += __hip_atomic_load(&tot[k * 4u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                scr += __hip_atomic_load(&tot[k * 4u + 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (v != 0xFFFFFFFFu) blk_out[k] = make_uint2(base_r + (v & 0xFFFFu), v >> 16);
         }
     }
 }

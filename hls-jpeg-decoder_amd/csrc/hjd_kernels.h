@@ -32,17 +32,18 @@ struct HjdParams {
     uint32_t tk_n, tk_nwg, epoch;
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
-    uint2 *blk;                // per block: first record index; DC running sum within its final-pass workgroup | workgroup << 16 (hjd_device.h)
-    uint4 *wgdc;               // [wgdc_n] per final-pass workgroup: DC sums (Y, Cb, Cr); [wgdc_n .. 2 wgdc_n): their exclusive prefixes per image
-    uint32_t wgdc_n;
+    uint2 *blk;                // per block: first record index, DC difference as decoded (k_write)
+    int16_t *dca;              // per block: DC value after prediction
     // workgroup -> image for every kernel's workgroup numbering (global numbers, like the off_* below)
-    const uint32_t *map_chunk, *map_syncwg, *map_syncwg_small, *map_repwg, *map_writewg, *map_writewg_small;
+    const uint32_t *map_chunk, *map_syncwg, *map_syncwg_small, *map_repwg, *map_writewg, *map_writewg_small, *map_dcchunk;
     const uint2 *map_group;    // IDCT/colour workgroup -> (image, absolute index of its first block in blk)
+    uint32_t *dcsum;           // per DC chunk: totals of the Y, Cb, Cr differences
+    uint32_t ndcchunks;
     uint8_t *out;              // RGB / BMP bytes
     int nimg;
     // A launch may cover only a contiguous range of images (sub-batches on separate streams): these are
     // added to blockIdx.x so that every kernel still sees batch-global workgroup / image numbers.
-    uint32_t off_chunk, off_syncwg, off_syncwg_small, off_repwg, off_writewg, off_writewg_small, off_img, off_group;
+    uint32_t off_chunk, off_syncwg, off_syncwg_small, off_repwg, off_writewg, off_writewg_small, off_img, off_dcchunk, off_group;
     uint32_t conformant;       // hjd_options.conformant: selects the conformant instantiation of the back end
     uint32_t gate_emulated;    // k_idct_color: 1 = only images the sequential emulation has just decoded (HjdImageState::emulated)
     const uint32_t *seq_list;  // k_sync_seq: per workgroup 64 device images (all ones = none) that share table set and sampling
@@ -78,6 +79,7 @@ struct HjdParams {
 
 int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s); // mode 0 k_sync, 1 k_repair, 2 k_repair_totals, 3 k_sync_small
+int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s);
 int hjd_launch_write(const HjdParams &P, uint32_t nwg, hipStream_t s, int small = 0);
 int hjd_launch_sync_seq(const HjdParams &P, uint32_t nwg, hipStream_t s);
 int hjd_launch_idct_color(const HjdParams &P, uint32_t ngroups, hipStream_t s);

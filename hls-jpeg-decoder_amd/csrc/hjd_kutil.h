@@ -92,28 +92,3 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t &a, uint32_t &b, uint3
     b = pb + ib - b;
 }
 
-
-// three values at once: exclusive prefixes over the block's lanes, in place, and the block sums (one barrier; s3: >= 48 words that
-// nothing else touches until the next barrier)
-__device__ __forceinline__ void block_excl_scan3(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t *s3, uint32_t *ta, uint32_t *tb, uint32_t *tc)
-{
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    uint32_t ia = a, ib = b, ic = c;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t xa = __shfl_up(ia, d, WAVE), xb = __shfl_up(ib, d, WAVE), xc = __shfl_up(ic, d, WAVE);
-        if (lane >= d) ia += xa, ib += xb, ic += xc;
-    }
-    if (lane == WAVE - 1) s3[wv * 3] = ia, s3[wv * 3 + 1] = ib, s3[wv * 3 + 2] = ic;
-    __syncthreads();
-    uint32_t pa = 0, pb = 0, pc = 0, sa = 0, sb = 0, sc = 0;
-    for (int i = 0; i < nw; i++) {
-        const uint32_t xa = s3[i * 3], xb = s3[i * 3 + 1], xc = s3[i * 3 + 2];
-        sa += xa, sb += xb, sc += xc;
-        pa += i < wv ? xa : 0u, pb += i < wv ? xb : 0u, pc += i < wv ? xc : 0u;
-    }
-    *ta = sa, *tb = sb, *tc = sc;
-    a = pa + ia - a;
-    b = pb + ib - b;
-    c = pc + ic - c;
-}

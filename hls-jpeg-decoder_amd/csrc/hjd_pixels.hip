@@ -258,13 +258,12 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
     const uint32_t nb = im.nb, nby = im.nby;
     const uint32_t KB = K * nb;
 
-    // the group's block entries: its record range (first record of its first block, first record of the block after its last) and
-    // the DC values in the form k_write leaves them (running sum inside a final-pass workgroup | that workgroup's number) —
-    // independent of the image fields
-    uint2 ent = make_uint2(0u, 0u);
-    if (tid <= KB) ent = P.blk[gm.y + tid];
-    const uint32_t bfirst = ent.x;
+    // the group's record range (first record of its first block, first record of the block after its last) and the predicted
+    // DC values — independent of the image fields
+    uint32_t bfirst = 0u;
     int dc = 0;
+    if (tid == 0 || tid == KB) bfirst = P.blk[gm.y + tid].x;
+    if (tid < KB) dc = P.dca[gm.y + tid];
     constexpr bool conf = CONF;
     if (tid < 64) {
         s_cos[tid] = conf ? c_cos_true[(tid & 7) * 8 + (tid >> 3)] : c_cos[(tid & 7) * 8 + (tid >> 3)];
@@ -289,20 +288,13 @@ __global__ __launch_bounds__(256) HJD_IDCT_OCC void k_idct_color(HjdParams P)
         s_mask[tid][1] = 0u;
     }
     __syncthreads();
-    if (tid < KB) { // DC prediction (loadjpg.cpp:619-667, :1159-1162: a running sum per component, int16 wrap): k_write's running sum
-                    // inside its workgroup + the sums of the workgroups before it; quantiser slot 0 (DequantizeBlock, :144-152: int16 wrap)
-        auto dc_value = [&](const uint2 e, uint32_t comp) -> int {
-            const uint32_t wgi = e.y >> 16; // 0xFFFF: the emulation kernels leave the DC value itself
-            const uint32_t base = wgi == 0xFFFFu ? 0u : reinterpret_cast<const uint32_t *>(P.wgdc + P.wgdc_n + im.wgsum0 + wgi)[comp];
-            return (int)(int16_t)((e.y & 0xFFFFu) + base);
-        };
-        dc = dc_value(ent, mycomp);
+    if (tid < KB) { // DC: predicted value from k_dcapply, quantiser slot 0 (DequantizeBlock, loadjpg.cpp:144-152: int16 wrap)
         if (conf && im.ri_blocks) {
             // conformant mode: predictors restart with every interval = the running sum minus its value at the
             // end of the previous interval (the reference, and the default mode, carry it across: loadjpg.cpp:1159-1162)
             const uint32_t ri = im.ri_blocks / nb, mcu = (uint32_t)(gm.y - im.blk_off + tid) / nb;
             const uint32_t s0 = mcu - mcu % ri;
-            if (s0) dc = (int)(int16_t)(dc - dc_value(P.blk[im.blk_off + (size_t)(s0 - 1u) * nb + (mycomp == 0 ? nby - 1u : nby + mycomp - 1u)], mycomp));
+            if (s0) dc = (int)(int16_t)(dc - (int)P.dca[im.blk_off + (size_t)(s0 - 1u) * nb + (mycomp == 0 ? nby - 1u : nby + mycomp - 1u)]);
         }
         const int16_t nat = (int16_t)(dc * (int)s_qt[mycomp][0]);
         s_coef[tid][0] = nat;

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
     r.idx = r.res = r.nbits = 0u; // loadjpg.cpp:1148-1149
     uint32_t *rec = P.rec + im.rec_off;
     uint2 *blk = P.blk + im.blk_off;
+    int16_t *dca = P.dca + im.blk_off;
     int prev[3] = {0, 0, 0}; // :1159-1162, never reset afterwards
     uint32_t nrec = 0, flags = 0;
     const bool restart = im.restart != 0;
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(64) void k_seq_decode(HjdParams P, uint32_t first, 
         flags |= seq_block<true>(r, s_lut, ts, im, restart, comp, b, &diff, nrec, rec);
         if (flags) break;
         prev[comp] = (int)(int16_t)(diff + prev[comp]); // :664
-        blk[b] = make_uint2(first_rec, ((uint32_t)prev[comp] & 0xFFFFu) | 0xFFFF0000u); // the predicted DC itself (workgroup 0xFFFF: no base is added)
+        blk[b] = make_uint2(first_rec, 0u); // the back end takes the predicted DC from dca[], the slots its records fill from the records
+        dca[b] = (int16_t)prev[comp];
     }
     blk[im.nblocks] = make_uint2(min(nrec, im.rec_cap), 0u);
     HjdImageState &st = P.st[ii];
@@ -577,7 +579,8 @@ __global__ __launch_bounds__(SEG_WG) void k_seg_write(HjdParams P)
         seg_start(r, P, im, j);
         uint32_t *rec = P.rec + im.rec_off;
         uint2 *blk = P.blk + im.blk_off;
-            int prev[3] = {(int)(int16_t)(base.z & 0xFFFFu), (int)(int16_t)(base.z >> 16), (int)(int16_t)(base.w & 0xFFFFu)};
+        int16_t *dca = P.dca + im.blk_off;
+        int prev[3] = {(int)(int16_t)(base.z & 0xFFFFu), (int)(int16_t)(base.z >> 16), (int)(int16_t)(base.w & 0xFFFFu)};
         uint32_t b = b0, nrec = base.y, flags = 0;
         bool check = j == 0u;
         while (b < im.nblocks) {
@@ -589,7 +592,8 @@ __global__ __launch_bounds__(SEG_WG) void k_seg_write(HjdParams P)
             flags = seq_block<true>(r, s_lut, ts, im, true, comp, b, &diff, nrec, rec);
             if (flags) break;
             prev[comp] = (int)(int16_t)(diff + prev[comp]);
-            blk[b] = make_uint2(first_rec, ((uint32_t)prev[comp] & 0xFFFFu) | 0xFFFF0000u);
+            blk[b] = make_uint2(first_rec, 0u);
+            dca[b] = (int16_t)prev[comp];
             b++;
         }
         if (flags) { // the true decode fails here, before its last block: k_seq_decode's verdict

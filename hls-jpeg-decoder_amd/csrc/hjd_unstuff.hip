@@ -1,5 +1,7 @@
-// hjd_unstuff.hip — byte-level preparation of the scan (gfx950).
+// hjd_unstuff.hip — byte-level preparation of the scan and the prefix sums between the two
+// entropy passes (gfx950).
 //   k_unstuff_count / k_unstuff_write  bit-reader byte rule FF00 -> FF      (loadjpg.cpp:468-482)
+//   k_dcsum / k_dcapply                DC prediction as a prefix sum          (loadjpg.cpp:619-667, :1159-1162)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -283,6 +285,127 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
     }
 }
 
+// ---- stage 3b: DC prediction --------------------------------------------------------------------
+// DCT[0] = diff + previousDC per component, predictors zeroed once per image and never reset
+// (loadjpg.cpp:619-667, :1159-1162), int16 wrap (loadjpg.cpp:664-665) = prefix sums mod 2^16 over the
+// blocks of each component in decode order.  Two passes over chunks of HJD_DC_CHUNK MCUs:
+// k_dcsum (per-chunk totals), k_dcapply (totals of the earlier chunks + scan inside the chunk).
+// The differences sit in the blocks' 8-byte entries (blk[].y, written by k_write together with the first-record index: one store
+// per block); the predicted values go to the compact array dca[] (a thread's 2-byte stores are contiguous: whole sectors
+// leave the wave).
+
+#define DC_T (HJD_DC_CHUNK / 256) // MCUs per thread
+
+__device__ __forceinline__ uint32_t dc_diff(const uint2 &e) { return (uint32_t)(int)(int16_t)e.y; }
+
+__device__ __forceinline__ void dc_thread_sums(const uint2 *d, uint32_t m0, uint32_t m1, uint32_t nb, uint32_t nby,
+                                               uint32_t &y, uint32_t &cb, uint32_t &cr)
+{
+    y = cb = cr = 0;
+    for (uint32_t mc = m0; mc < m1; mc++) {
+        const uint2 *q = d + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) y += dc_diff(q[k]);
+        cb += dc_diff(q[nby]);
+        cr += dc_diff(q[nby + 1]);
+    }
+}
+
+// Three sums at once over a workgroup of 256 lanes, ONE barrier each (three block_excl_scan calls were nine; these two kernels are
+// nothing but latency).  s: 12 words of LDS that nothing else touches until the next barrier.
+__device__ __forceinline__ void block_sum3(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t *s)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+        c += __shfl_xor(c, d, 64);
+    }
+    if (lane == 0) s[wv * 3u] = a, s[wv * 3u + 1u] = b, s[wv * 3u + 2u] = c;
+    __syncthreads();
+    a = s[0] + s[3] + s[6] + s[9];
+    b = s[1] + s[4] + s[7] + s[10];
+    c = s[2] + s[5] + s[8] + s[11];
+}
+
+// exclusive prefixes of three values over the workgroup's lanes, in place
+__device__ __forceinline__ void block_excl_scan3(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t *s)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b, ic = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64), tc = __shfl_up(ic, d, 64);
+        if ((int)lane >= d) ia += ta, ib += tb, ic += tc;
+    }
+    if (lane == 63u) s[wv * 3u] = ia, s[wv * 3u + 1u] = ib, s[wv * 3u + 2u] = ic;
+    __syncthreads();
+    uint32_t pa = 0, pb = 0, pc = 0;
+    for (uint32_t k = 0; k < wv; k++) pa += s[k * 3u], pb += s[k * 3u + 1u], pc += s[k * 3u + 2u];
+    a = pa + ia - a;
+    b = pb + ib - b;
+    c = pc + ic - c;
+}
+
+__global__ __launch_bounds__(256) void k_dcsum(HjdParams P)
+{
+    __shared__ uint32_t s_w[12];
+    const uint32_t bid = blockIdx.x + P.off_dcchunk;
+    const int ii = (int)P.map_dcchunk[bid];
+    const HjdImage &im = P.img[ii];
+    const uint32_t nmcu = im.mcux * im.mcuy;
+    const uint32_t c0 = (bid - im.dcchunk0) * HJD_DC_CHUNK;
+    const uint32_t m0 = min(c0 + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
+    uint32_t y, cb, cr;
+    dc_thread_sums(P.blk + im.blk_off, m0, m1, im.nb, im.nby, y, cb, cr);
+    block_sum3(y, cb, cr, s_w);
+    if (threadIdx.x == 0) {
+        P.dcsum[bid * 3 + 0] = y;
+        P.dcsum[bid * 3 + 1] = cb;
+        P.dcsum[bid * 3 + 2] = cr;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dcapply(HjdParams P)
+{
+    __shared__ uint32_t s_a[12], s_b[12];
+    const uint32_t bid = blockIdx.x + P.off_dcchunk;
+    const int ii = (int)P.map_dcchunk[bid];
+    const HjdImage &im = P.img[ii];
+    const uint32_t nb = im.nb, nby = im.nby;
+    const uint32_t nmcu = im.mcux * im.mcuy;
+    const uint32_t lc = bid - im.dcchunk0;
+    // totals of this image's earlier chunks
+    uint32_t by = 0, bcb = 0, bcr = 0;
+    for (uint32_t k = threadIdx.x; k < lc; k += blockDim.x) {
+        by += P.dcsum[(im.dcchunk0 + k) * 3 + 0];
+        bcb += P.dcsum[(im.dcchunk0 + k) * 3 + 1];
+        bcr += P.dcsum[(im.dcchunk0 + k) * 3 + 2];
+    }
+    const uint32_t m0 = min(lc * HJD_DC_CHUNK + threadIdx.x * DC_T, nmcu), m1 = min(m0 + DC_T, nmcu);
+    const uint2 *d = P.blk + im.blk_off;
+    int16_t *o = P.dca + im.blk_off;
+    uint32_t y, cb, cr;
+    dc_thread_sums(d, m0, m1, nb, nby, y, cb, cr); // (its loads are in flight while the totals are added up)
+    block_sum3(by, bcb, bcr, s_a);
+    block_excl_scan3(y, cb, cr, s_b);
+    y += by;
+    cb += bcb;
+    cr += bcr;
+    for (uint32_t mc = m0; mc < m1; mc++) {
+        const uint2 *q = d + (size_t)mc * nb;
+        int16_t *w = o + (size_t)mc * nb;
+        for (uint32_t k = 0; k < nby; k++) {
+            y += dc_diff(q[k]);
+            w[k] = (int16_t)y; // int16 wrap of the predictor (loadjpg.cpp:664-665)
+        }
+        cb += dc_diff(q[nby]);
+        w[nby] = (int16_t)cb;
+        cr += dc_diff(q[nby + 1]);
+        w[nby + 1] = (int16_t)cr;
+    }
+}
+
 #define HJD_LAUNCH_CHECK()                         \
     do {                                           \
         hipError_t e_ = hipGetLastError();         \
@@ -295,6 +418,16 @@ int hjd_launch_unstuff(const HjdParams &P, uint32_t nchunks, hipStream_t s)
     hipLaunchKernelGGL(k_unstuff_count, dim3(nchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_unstuff_write, dim3(nchunks), dim3(256), 0, s, P);
+    HJD_LAUNCH_CHECK();
+    return 0;
+}
+
+int hjd_launch_dcscan(const HjdParams &P, uint32_t nchunks, hipStream_t s)
+{
+    if (!nchunks) return 0;
+    hipLaunchKernelGGL(k_dcsum, dim3(nchunks), dim3(256), 0, s, P);
+    HJD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_dcapply, dim3(nchunks), dim3(256), 0, s, P);
     HJD_LAUNCH_CHECK();
     return 0;
 }

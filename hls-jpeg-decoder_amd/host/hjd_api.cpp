@@ -179,7 +179,7 @@ struct hjd_batch {
     int out_format = 0;
     // sub-batches: contiguous ranges of device images, each enqueued on its own internal stream between a fork
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
-    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, seq0, nseq, side_feeds_big, group0, ngroup; size_t blk0, nblk; };
+    struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, seq0, nseq, side_feeds_big, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
     std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
@@ -201,8 +201,8 @@ struct hjd_batch {
     hipStream_t seq_stream = nullptr;
     hipEvent_t seq_fork = nullptr, seq_done = nullptr;
     bool seq_pending = false;
-    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, nwritewg_small = 0, ngroups = 0;
-    uint4 *d_wgdc = nullptr; // per final-pass workgroup: DC sums, then their exclusive prefixes per image (HjdParams::wgdc)
+    uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, nwritewg_small = 0, ngroups = 0, ndcchunks = 0;
+    uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
     uint32_t *d_chunk_mark = nullptr, *d_mpos = nullptr;
     uint8_t *d_mval = nullptr;
@@ -228,6 +228,7 @@ struct hjd_batch {
     unsigned long long *d_dbg = nullptr; // HJD_SYNC_PROF=1: k_sync's per-workgroup clock stamps
     uint2 *d_wgsum = nullptr;
     uint2 *d_blk = nullptr;
+    int16_t *d_dca = nullptr;
     uint32_t *d_rec = nullptr;
     uint32_t *d_maps = nullptr; // workgroup -> image tables of all kernels, one allocation
     // A batch object can be re-prepared in place (hjd_batch_reset): slabs are only re-allocated when the new
@@ -418,8 +419,9 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_wgsum);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_blk);
+    (void)hipFree(b->d_dca);
     (void)hipFree(b->d_maps);
-    (void)hipFree(b->d_wgdc);
+    (void)hipFree(b->d_dcsum);
     for (auto &ss : b->small_side) {
         if (ss.st) (void)hipStreamDestroy(ss.st);
         if (ss.fork) (void)hipEventDestroy(ss.fork);
@@ -462,7 +464,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     b->out_bytes.clear();
     b->hdr_bytes.clear();
     b->ranges.clear();
-    b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->nwritewg_small = b->ngroups = b->nmarks = 0;
+    b->nchunks = b->nsub = b->nsyncwg = b->nsyncwg_small = b->nrepwg = b->nwritewg = b->nwritewg_small = b->ngroups = b->ndcchunks = b->nmarks = 0;
     b->pixels = b->alg_bytes = b->scan_bytes = 0;
     b->resyncs = 0;
     b->dirty_decodes = b->segment_decodes = 0;
@@ -524,12 +526,6 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         im.mcuy = (im.height + 8 * im.vf - 1) / (8 * im.vf);
         im.nblocks = im.mcux * im.mcuy * im.nb;
         im.scan_len = (uint32_t)j.stream_len;
-        if (((uint64_t)im.scan_len * 8 + S - 1) / S * nu / HJD_WRITE_WG >= 0xFFF0u) {
-            // the block entries name their final-pass workgroup in 16 bits (0xFFFF: none).  Out of reach at the automatic subsequence
-            // sizes (2^28 scan bytes = 16384 workgroups); a 64-bit hjd_options.subseq_bits on a scan beyond 130 MB is not
-            b->parse_status[i] = HJD_ERR_UNSUPPORTED;
-            continue;
-        }
         const std::string key = tabset_key(j);
         auto it = tab_index.find(key);
         if (it == tab_index.end()) {
@@ -584,6 +580,9 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             im.nwritewg = (uint32_t)(((uint64_t)im.nsub_cap * nu + HJD_WRITE_WG - 1) / HJD_WRITE_WG);
             b->nwritewg += im.nwritewg;
         }
+        im.dcchunk0 = b->ndcchunks;
+        im.ndcchunk = (im.mcux * im.mcuy + HJD_DC_CHUNK - 1) / HJD_DC_CHUNK;
+        b->ndcchunks += im.ndcchunk;
         im.group0 = b->ngroups;
         im.groups_per_row = (im.mcux + HJD_GROUP_MCUS - 1) / HJD_GROUP_MCUS;
         im.ngroups = im.groups_per_row * im.mcuy;
@@ -772,12 +771,13 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
     need(slab_reserve(b, b->d_blk, sizeof(uint2) * (blk_cur + 1)));
-    need(slab_reserve(b, b->d_wgdc, sizeof(uint4) * 2 * (b->nwritewg + b->nwritewg_small + 1)));
+    need(slab_reserve(b, b->d_dca, sizeof(int16_t) * (blk_cur + 2)));
+    need(slab_reserve(b, b->d_dcsum, sizeof(uint32_t) * 3 * (b->ndcchunks + 1)));
     if (rcs != HJD_OK) return rcs;
     HIPCHK(hipMemsetAsync(b->d_blk, 0, sizeof(uint2) * (blk_cur + 1), up));
     std::vector<uint32_t> maps;
     {   // workgroup -> image for every kernel's workgroup numbering; IDCT groups also get their first block
-        size_t off_chunk = 0, off_sync, off_rep, off_write, off_group;
+        size_t off_chunk = 0, off_sync, off_rep, off_write, off_dc, off_group;
         auto fill = [&](uint32_t HjdImage::*first, uint32_t HjdImage::*count) {
             const size_t at = maps.size();
             for (int k = 0; k < b->nimg; k++) {
@@ -813,7 +813,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         off_write = fill_write(0u);
         const size_t off_write_small = fill_write(1u);
         if (off_write_small == (size_t)-1) return HJD_ERR_INTERNAL;
-        if (off_chunk == (size_t)-1 || off_sync == (size_t)-1 || off_rep == (size_t)-1 || off_write == (size_t)-1)
+        off_dc = fill(&HjdImage::dcchunk0, &HjdImage::ndcchunk);
+        if (off_chunk == (size_t)-1 || off_sync == (size_t)-1 || off_rep == (size_t)-1 || off_write == (size_t)-1 || off_dc == (size_t)-1)
             return HJD_ERR_INTERNAL;
         const size_t off_rst = maps.size(); // the sequential emulation's candidates
         maps.insert(maps.end(), b->rst_images.begin(), b->rst_images.end());
@@ -840,6 +841,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->P.map_repwg = b->d_maps + off_rep;
         b->P.map_writewg = b->d_maps + off_write;
         b->P.map_writewg_small = b->d_maps + off_write_small;
+        b->P.map_dcchunk = b->d_maps + off_dc;
         b->P.map_group = reinterpret_cast<const uint2 *>(b->d_maps + off_group);
         b->P.rst_list = b->d_maps + off_rst;
         b->P.rst_groups = b->d_maps + off_rstg;
@@ -919,11 +921,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.wgsum = b->d_wgsum;
     P.rec = b->d_rec;
     P.blk = b->d_blk;
-    P.wgdc = b->d_wgdc;
-    P.wgdc_n = b->nwritewg + b->nwritewg_small + 1;
+    P.dca = b->d_dca;
+    P.dcsum = b->d_dcsum;
+    P.ndcchunks = b->ndcchunks;
     P.out = b->d_out;
     P.nimg = b->nimg;
-    P.off_chunk = P.off_syncwg = P.off_syncwg_small = P.off_repwg = P.off_writewg = P.off_writewg_small = P.off_img = P.off_group = 0;
+    P.off_chunk = P.off_syncwg = P.off_syncwg_small = P.off_repwg = P.off_writewg = P.off_writewg_small = P.off_img = P.off_dcchunk = P.off_group = 0;
     {   // sub-batch ranges: contiguous runs of images with about equal pixel counts
         uint64_t total_px = 0;
         for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
@@ -980,6 +983,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                     }
                 }
             }
+            r.dc0 = a.dcchunk0;        r.ndc = z.dcchunk0 + z.ndcchunk - a.dcchunk0;
             r.group0 = a.group0;       r.ngroup = z.group0 + z.ngroups - a.group0;
             r.blk0 = (size_t)a.blk_off;
             r.nblk = (size_t)(z.blk_off + z.nblocks + 1 - a.blk_off);
@@ -1110,6 +1114,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->write_wg = HJD_WRITE_WG;
     o->group_mcus = HJD_GROUP_MCUS;
     o->unstuff_chunk = HJD_UNSTUFF_CHUNK;
+    o->dc_chunk = HJD_DC_CHUNK;
     o->rec_run = HJD_REC_RUN;
     o->nblocks = im.nblocks;
     o->mcux = im.mcux;
@@ -1120,6 +1125,7 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->nsyncwg = im.nsyncwg;
     o->nrepwg = im.nrepwg;
     o->nwritewg = im.nwritewg;
+    o->ndcchunk = im.ndcchunk;
     o->ngroups = im.ngroups;
     o->groups_per_row = im.groups_per_row;
     o->mark_cap = im.mark_cap;
@@ -1128,11 +1134,12 @@ extern "C" int hjd_layout_query(const hjd_jpeg_data *j, int subseq_bits, int syn
     o->raw_bytes = b.raw_bytes;
     o->ustream_bytes = b.ustream_bytes;
     o->blk_entries = b.nblk_entries + 1;       // what batch_build allocates
+    o->dca_entries = b.nblk_entries + 2;
     o->rec_entries = b.nrec + HJD_REC_RUN;
     o->out_bytes = b.out_total;
     o->substate_entries = b.nsub;
     o->wgsum_entries = (size_t)b.nwritewg + b.nwritewg_small;
-    o->wgdc_entries = 2 * ((size_t)b.nwritewg + b.nwritewg_small + 1);
+    o->dcsum_entries = 3 * ((size_t)b.ndcchunks + 1);
     {   // what batch_build allocates
         const size_t nph = (b.P.subseq_bits / 32) / b.P.phase_words;
         o->ckpt_entries = (size_t)b.nsub * nph + (size_t)b.nsyncwg * nph * b.P.sync_overlap + 1;
@@ -1223,6 +1230,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     P.off_writewg = r.writewg0;
     P.off_writewg_small = r.swritewg0;
     P.off_img = (uint32_t)r.i0;
+    P.off_dcchunk = r.dc0;
     P.off_group = r.group0;
     int k = 0;
     auto mark = [&](const char *name) -> int {
@@ -1314,7 +1322,8 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         return HJD_ERR_INTERNAL;
     }
     if (record_stagger && stagger_after == 2 && !from_resync && hipEventRecord(record_stagger, s) != hipSuccess) return HJD_ERR_INTERNAL;
-    // (DC prediction: until round 4 two launches of their own here; now k_write's epilogue and the back end's prologue)
+    if ((rc = mark("dc_scan"))) return rc;
+    if (hjd_launch_dcscan(P, r.ndc, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
     if (hjd_launch_idct_color(P, r.ngroup, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("end"))) return rc;
@@ -1379,6 +1388,7 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         all.nrepwg = b->nrepwg;
         all.nwritewg = b->nwritewg;
         all.nswritewg = b->nwritewg_small;
+        all.ndc = b->ndcchunks;
         all.ngroup = b->ngroups;
         all.nblk = b->nblk_entries;
         all.nrst = (uint32_t)b->rst_images.size();
@@ -1526,7 +1536,6 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             for (auto &st : b->state) {
                 st.flags &= HJD_FLAG_BAD_MARKER;
                 st.emulated = 0;
-                st.wg_done = 0; // the final pass runs again: its workgroups count themselves anew
             }
             b->resyncs++;
             // keep ustream_len, nmarkers
@@ -1595,20 +1604,13 @@ extern "C" int hjd_batch_download_coefs(hjd_batch *b, int i, int16_t *dst, size_
     std::vector<uint32_t> rec(im.rec_cap);
     uint8_t slot_to_zz[64];
     for (int k = 0; k < 64; k++) slot_to_zz[kZzToSlot[k]] = (uint8_t)k;
-    // DC values: the running sum inside the final-pass workgroup that decoded the block's DC symbol + the sums of the workgroups
-    // before it (csrc/hjd_device.h: blk, wgdc) — what the back end computes
-    std::vector<uint4> wgdc(2 * (size_t)b->P.wgdc_n);
-    HIPCHK(hipMemcpy(wgdc.data(), b->d_wgdc, wgdc.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    std::vector<int16_t> dca(im.nblocks);
     HIPCHK(hipMemcpy(blk.data(), b->d_blk + im.blk_off, blk.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dca.data(), b->d_dca + im.blk_off, dca.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rec.data(), b->d_rec + im.rec_off, rec.size() * 4, hipMemcpyDeviceToHost));
     memset(dst, 0, ne * 2);
     for (uint32_t k = 0; k < im.nblocks; k++) {
-        {
-            const uint32_t mm = k % im.nb, comp = mm < im.nby ? 0u : mm - im.nby + 1u, wgi = blk[k].y >> 16;
-            const uint4 &bs = wgdc[(size_t)b->P.wgdc_n + im.wgsum0 + (wgi == 0xFFFFu ? 0u : wgi)];
-            const uint32_t base = wgi == 0xFFFFu ? 0u : (comp == 0 ? bs.x : (comp == 1 ? bs.y : bs.z));
-            dst[(size_t)k * 64] = (int16_t)((blk[k].y & 0xFFFFu) + base);
-        }
+        dst[(size_t)k * 64] = dca[k];
         for (uint32_t t = blk[k].x; t < blk[k + 1].x && t < im.rec_cap; t++)
             if (rec[t] != HJD_REC_PAD) dst[(size_t)k * 64 + slot_to_zz[(rec[t] >> 16) & 63]] = (int16_t)(rec[t] & 0xFFFF);
     }

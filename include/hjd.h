@@ -248,11 +248,11 @@ int hjd_test_color_table(hjd_decoder *d, uint8_t *dst, size_t dst_cap);
  * `j` matter; `stream` must be non-NULL but is not read).  tests/test_layout_bounds.py recomputes from it the
  * largest element every kernel may touch in every slab. */
 typedef struct hjd_layout_info {
-    uint32_t subseq_bits, sync_overlap, phase_words, sync_wg, write_wg, group_mcus, unstuff_chunk, rec_run;
-    uint32_t nblocks, mcux, mcuy, nb, nchunks, nsub_cap, nsyncwg, nrepwg, nwritewg, ngroups, groups_per_row;
+    uint32_t subseq_bits, sync_overlap, phase_words, sync_wg, write_wg, group_mcus, unstuff_chunk, dc_chunk, rec_run;
+    uint32_t nblocks, mcux, mcuy, nb, nchunks, nsub_cap, nsyncwg, nrepwg, nwritewg, ndcchunk, ngroups, groups_per_row;
     uint32_t mark_cap, rec_cap, out_stride, lds_bytes_sync, lds_bytes_write, lds_state_word, lds_state_word_sync;
-    uint64_t raw_bytes, ustream_bytes, blk_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
-        wgdc_entries, ckpt_entries;
+    uint64_t raw_bytes, ustream_bytes, blk_entries, dca_entries, rec_entries, out_bytes, substate_entries, wgsum_entries,
+        dcsum_entries, ckpt_entries;
     /* segment-parallel emulation of dirty restart streams (csrc/hjd_seq.hip; all 0 without DRI): candidates reserved, nodes
      * (= (seg_cap + 1) * nb), bytes of the slab that holds the candidate list, the per-node arrays, counters and plans */
     uint64_t seg_cap, seg_nodes, seg_slab_bytes;

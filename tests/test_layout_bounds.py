@@ -96,15 +96,14 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
         else:
             assert nsub * nph + ((o.nsyncwg - 1) * nph + nph - 1) * K + max(K, 1) - 1 < o.ckpt_entries
         # --- blocks: k_write stores blk[b] for b <= nblocks (closing entry); the IDCT kernel loads blk[b0 + tid], tid <= KB,
-        #     for the last group of the last MCU row: b0 + KB == nblocks
+        #     and dca[b0 + tid], tid < KB, for the last group of the last MCU row: b0 + KB == nblocks
         assert o.nblocks == mcus * o.nb and o.nb == hf * vf + 2
-        assert o.nblocks + 1 <= o.blk_entries
+        assert o.nblocks + 1 <= o.blk_entries and o.nblocks <= o.dca_entries
         # --- records: every store and every 16-byte load is guarded by rec_cap; the slab holds one burst more
         assert o.rec_cap % o.rec_run == 0 and o.rec_cap + o.rec_run <= o.rec_entries
         assert o.rec_cap >= min(o.nblocks * 63, scan_len * 8 // 2) + o.rec_run * nsub * nph   # a record costs at least two scan bits; every window's run is padded
-        # --- DC sums: k_write workgroup wq < nwritewg writes wgdc[wq], the image's last one wgdc[n + wq], n = wgdc_entries / 2;
-        #     the back end reads wgdc[n + wq] for the workgroup numbers k_write put into the block entries
-        assert o.wgdc_entries % 2 == 0 and o.nwritewg < o.wgdc_entries // 2 and o.nwritewg < 0xFFFF   # 0xFFFF in an entry: "the DC value itself"
+        # --- DC chunks cover every MCU; dcsum holds three sums per chunk
+        assert o.ndcchunk * o.dc_chunk >= mcus and 3 * o.ndcchunk <= o.dcsum_entries
         # --- IDCT groups: groups_per_row * mcuy workgroups of <= group_mcus MCUs
         assert o.groups_per_row * o.group_mcus >= o.mcux and o.ngroups == o.groups_per_row * o.mcuy
         # --- output: the last byte written is pixel (W-1, H-1) (RGB) or the end of the top row incl. padding (BMP)
