@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic: no hipEvents between the kernels of the timed steps")
+    ap.add_argument("--stage-events", choices=("one", "all"), default="one",
+                    help="which launches of a step carry stage hipEvents in the reported region: those of ONE stream (default: every "
+                         "step has one instrumented launch — the events cost a launch 3-4 %%, profiles/r05_stage_events.txt) or of all")
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of --steps steps after the reported one: their values are listed as `spread`")
     args = ap.parse_args()
 
@@ -319,9 +322,9 @@ def main():
         st = b.finish(sh)
         assert all(s == 0 for s in st), st
 
-    if args.internal_streams <= 1 and not args.no_stage_events:
-        for b in batches:
-            b.enable_timing(args.steps)
+    timed_batches = [] if (args.internal_streams > 1 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
+    for b in timed_batches:
+        b.enable_timing(args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -347,10 +350,11 @@ def main():
         if b.resync_count() != 0:
             raise SystemExit("bench: the timed steps needed a host-driven re-synchronisation (%d rounds): "
                              "their outputs were not final inside the timed region" % b.resync_count())
-        stg, runs = b.collect_timing()
-        stages_all.append(stg)
+        if b in timed_batches:
+            stg, runs = b.collect_timing()
+            stages_all.append(stg)
     # per-launch stage durations INSIDE the timed region: other streams' kernels share the GPU (overlapped)
-    stages_ovl = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / ns) for k in range(len(stages_all[0]))] \
+    stages_ovl = [(stages_all[0][k][0], sum(sa[k][1] for sa in stages_all) / len(stages_all)) for k in range(len(stages_all[0]))] \
         if stages_all and stages_all[0] else []
     launch_alg_bytes = alg_bytes / ns
 
@@ -474,7 +478,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": per_kernel.get(dom[0], {}).get("traffic"),
-                "timing": timing + (": hipEvents around the stage inside the timed region, other streams' kernels beside it"
+                "timing": timing + (": hipEvents around the stage inside the timed region (the launches of %s), other streams' kernels beside it" % ("one of the %d streams: one launch per step" % ns if len(timed_batches) == 1 and ns > 1 else "every stream")
                                     if timing == "overlapped" else ": no stage events in the timed region"),
                 "kernel_ms": round(dom[1], 4),
                 "kernel_ms_isolated": round(iso.get(dom[0], 0.0), 4),

@@ -714,6 +714,142 @@ __device__ __forceinline__ void sync_window<1>(SyncChain (&ch)[1], const uint32_
         : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
 }
 
+// The same loop for restart streams (images with DRI; round 5).  Rounds 3-4 ran the C++ loops on them; the first form of this round
+// ran the plain hand-written loop up to 39 bits before every marker and the C++ rule loop around it, in alternating phases — but a
+// wave then walks a window up to twice (the lanes that met a marker finish their window while the others wait): 64 x 1080p with one
+// marker per MCU row 152 Gpixel/s against 182 without DRI.  Here the speculative form of the reference's marker rule
+// (loadjpg.cpp:535-550: its check fires at a block start when the byte cursor sits on the marker, i.e. when a block has ended inside
+// the last byte before it — or the decode has run over the marker altogether) is PART of the loop: three instructions in the shadow
+// of the look-up compare the position after the previous step (+ 8 when it ended a block) with the next marker's, and a lane that
+// trips is pulled onto the interval's start out of line (block 6: position, block table entry 0, bit reader, next marker), after
+// which every lane repeats its look-up.  Two-symbol steps stop 40 bits before the marker, as in sync_core<true>.
+// mrel / mrel2: positions of the next two markers relative to the window's first bit (0x7FFFFFFF: none); a lane that needs a third
+// one inside the window stops (its pend becomes its position) and the caller hands it the next two.  col: LDS byte address of the
+// lane's staging column; mt0: of block table entry 0.
+__device__ __forceinline__ void sync_window_rst(SyncChain &c, uint32_t &pend, uint32_t &mrel, uint32_t &mrel2, uint32_t col, uint32_t mt0,
+                                                uint32_t sec_addr)
+{
+    const uint32_t plimw = pend > 32u ? pend - 32u : 0u;
+    uint32_t plim = min(plimw, max(mrel, 40u) - 40u);
+    const uint32_t secm = sec_addr - 2u * HJD_SEC_SIZE_S;
+    uint32_t tb = c.z == 0u ? c.dcb : c.acb;
+    uint32_t win, a, w, nw, t, t2;
+    uint32_t e = 0u, tot = 0u;
+    unsigned long long act, pm, sv, jm, bm = 0ull;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_branch 1f\n"
+        "2:\n\t"                                             // ---- the look-up has been issued: is the step taken at all?
+        "s_and_b64 vcc, vcc, %[pm]\n\t"                    // two symbols as one step
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_lshrrev_b32_e32 %[e], 16, %[w]\n\t"
+        "v_cndmask_b32_e32 %[e], %[w], %[e], vcc\n\t"
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
+        "s_and_b64 %[pm], vcc, %[act]\n\t"                 // a live lane with a code longer than HJD_LUT_BITS_S?
+        "s_cbranch_scc1 4f\n"
+        "5:\n\t"
+        "v_cndmask_b32_e64 %[e], 0, %[e], %[act]\n\t"      // a lane at the end of its window stands still
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_bfe_u32 %[t], %[e], 5, 7\n\t"
+        "v_sub_u32_e32 %[sh], %[sh], %[tot]\n\t"
+        "v_add_u32_e32 %[z], %[z], %[t]\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, %[sh]\n\t"
+        "v_cmp_lt_u32_e64 %[bm], 63, %[z]\n\t"             // end of block
+        "v_and_b32_e32 %[t], 0x100, %[sh]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 %[hi], %[hi], %[lo], vcc\n\t"
+        "v_add_u32_e32 %[nxa], %[nxa], %[t]\n\t"
+        "v_cndmask_b32_e64 %[tb], %[acb], v120, %[bm]\n\t"
+        "v_cndmask_b32_e32 %[lo], %[lo], %[nw], vcc\n\t"
+        "v_cndmask_b32_e64 %[z], %[z], 0, %[bm]\n\t"
+        "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
+        "v_cndmask_b32_e64 %[mi], %[mi], v122, %[bm]\n\t"
+        "v_cndmask_b32_e64 %[acb], %[acb], v121, %[bm]\n"
+        "1:\n\t"                                             // ---- next look-up
+        "v_alignbit_b32 %[win], %[hi], %[lo], %[sh]\n\t"
+        "v_bfe_u32 %[a], %[win], %[lb], %[lw]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[tb]\n\t"
+        "ds_read_b32 %[w], %[a]\n\t"
+        "ds_read_b32 %[nw], %[nxa]\n\t"
+        "ds_read_b128 v[120:123], %[mi]\n\t"
+        // while the look-up is under way: what the previous step left to do, and the marker rule on the position it reached
+        "v_add_u32_e32 %[p], %[p], %[tot]\n\t"
+        "v_cndmask_b32_e64 %[t2], 0, 8, %[bm]\n\t"
+        "v_bfe_u32 %[t], %[e], 14, 2\n\t"
+        "v_add_u32_e32 %[t2], %[t2], %[p]\n\t"
+        "v_addc_co_u32_e64 %[nblk], %[sv], 0, %[nblk], %[bm]\n\t"
+        "v_cmp_gt_u32_e64 %[jm], %[t2], %[mrel]\n\t"       // block ended within the marker's last byte, or the decode ran over the marker
+        "v_cmp_lt_u32_e64 %[act], %[p], %[pend]\n\t"
+        "v_add_u32_e32 %[nrec], %[nrec], %[t]\n\t"
+        "s_cmp_lg_u64 %[jm], 0\n\t"
+        "s_cbranch_scc1 6f\n\t"
+        "v_cmp_gt_u32_e64 %[pm], 48, %[z]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[p], %[plim]\n\t"
+        "s_cmp_lg_u64 %[act], 0\n\t"
+        "s_cbranch_scc1 2b\n\t"
+        "s_branch 3f\n"
+        "4:\n\t"                                             // ---- second-level table on the next HJD_SEC_BITS_S bits
+        "s_and_saveexec_b64 %[sv], %[pm]\n\t"
+        "v_bfe_u32 %[t], %[e], 5, 11\n\t"
+        "v_bfe_u32 %[a], %[win], 16, %[sw]\n\t"
+        "v_lshl_add_u32 %[a], %[t], %[sw], %[a]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 1, %[secm]\n\t"
+        "ds_read_u16 %[a], %[a]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[t]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 %[e], 0, %[a], vcc\n\t"
+        "v_and_b32_e32 %[tot], 31, %[e]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[tot]\n\t"
+        "v_cndmask_b32_e64 %[e], %[e], 16, vcc\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_branch 5b\n"
+        "6:\n\t"                                             // ---- lanes %[jm] are pulled onto the start of the next interval
+        "s_waitcnt lgkmcnt(0)\n\t"                         // the look-ups issued above land before their registers are used again
+        "s_and_saveexec_b64 %[sv], %[jm]\n\t"
+        "v_mov_b32_e32 %[p], %[mrel]\n\t"                  // position = the marker's (the interval's first bit), block start, block 0 of an MCU
+        "v_mov_b32_e32 %[z], 0\n\t"
+        "ds_read_b128 v[120:123], %[mt0]\n\t"              // block table entry 0: DC table, AC table, entry of the next block
+        "v_min_u32_e32 %[a], %[p], %[pend]\n\t"            // (a jump past the window's end: the lane is done, its reader only has to stay inside the staged words)
+        "v_lshrrev_b32_e32 %[a], 5, %[a]\n\t"
+        "v_and_b32_e32 %[t2], 31, %[p]\n\t"                // bit offset inside the word
+        "v_lshl_add_u32 %[a], %[a], 8, %[col]\n\t"         // the word's LDS address (256 bytes between the words of a column)
+        "ds_read_b32 %[hi], %[a]\n\t"
+        "ds_read_b32 %[t], %[a] offset:256\n\t"
+        "v_sub_u32_e32 %[sh], 32, %[t2]\n\t"
+        "v_min_u32_e32 %[t2], 1, %[t2]\n\t"                // 1 when the position is inside a word: hi, lo = this word, the next
+        "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
+        "v_lshl_add_u32 %[t2], %[t2], 8, %[a]\n\t"
+        "v_add_u32_e32 %[nxa], 0x100, %[t2]\n\t"           // the word after hi (position at a word's start: lo = hi) or after lo
+        "v_mov_b32_e32 %[mrel], %[mrel2]\n\t"              // the marker after that one; the one after THAT is not known here
+        "v_mov_b32_e32 %[mrel2], 0x7ffffffe\n\t"
+        "v_max_u32_e32 %[t2], 40, %[mrel]\n\t"
+        "v_subrev_u32_e32 %[t2], 40, %[t2]\n\t"
+        "v_min_u32_e32 %[plim], %[plimw], %[t2]\n\t"       // two-symbol steps up to 40 bits before it
+        "v_cmp_eq_u32_e32 vcc, 0x7ffffffe, %[mrel]\n\t"
+        "v_cndmask_b32_e32 %[pend], %[pend], %[p], vcc\n\t" // a third marker inside this window: the lane stops here, the caller goes on
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[sh]\n\t"               // (sh = 0 <=> bit offset 0: lo = hi then)
+        "v_cndmask_b32_e32 %[lo], %[hi], %[t], vcc\n\t"
+        "v_mov_b32_e32 %[tb], v120\n\t"
+        "v_mov_b32_e32 %[acb], v121\n\t"
+        "v_mov_b32_e32 %[mi], v122\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_mov_b32_e32 %[e], 0\n\t"                        // nothing is left over from the step before (every lane: its counts have been added)
+        "v_mov_b32_e32 %[tot], 0\n\t"
+        "s_mov_b64 %[bm], 0\n\t"
+        "s_branch 1b\n"
+        "3:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [p] "+v"(c.p), [z] "+v"(c.z), [sh] "+v"(c.sh), [hi] "+v"(c.hi), [lo] "+v"(c.lo), [nxa] "+v"(c.nxa), [tb] "+v"(tb),
+          [acb] "+v"(c.acb), [mi] "+v"(c.mi), [nblk] "+v"(c.nblk), [nrec] "+v"(c.nrec), [e] "+v"(e), [tot] "+v"(tot), [bm] "+s"(bm),
+          [pend] "+v"(pend), [mrel] "+v"(mrel), [mrel2] "+v"(mrel2), [plim] "+v"(plim),
+          [win] "=&v"(win), [a] "=&v"(a), [w] "=&v"(w), [t] "=&v"(t), [t2] "=&v"(t2), [nw] "=&v"(nw), [act] "=&s"(act), [pm] "=&s"(pm), [sv] "=&s"(sv),
+          [jm] "=&s"(jm)
+        : [plimw] "v"(plimw), [secm] "v"(secm), [col] "v"(col), [mt0] "v"(mt0), [lb] "n"(32 - HJD_LUT_BITS_S), [lw] "n"(HJD_LUT_BITS_S), [sw] "n"(HJD_SEC_BITS_S)
+        : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
+}
+
 // What the decode of a window needs besides the chains' own state.
 struct RowEnv {
     const HjdParams *P;
@@ -770,93 +906,85 @@ __device__ __forceinline__ void decode_windows(const RowEnv &E, const bool (&liv
             for (uint32_t k = 0; k < WPP + 2u; k++) col[k * 64u] = src[k * 64u];
         }
     }
-    if (im.restart) {
-        // Restart streams (round 5): the stretches of a window that no marker rule can reach — everything more than 39 bits before
-        // the next marker: a step is at most 31 bits and the rules look 8 bits ahead — go through the hand-written loop like any
-        // other stream; only within reach of a marker does a lane run the loop that knows the reference's rules (sync_core<true>,
-        // loadjpg.cpp:535-550, :631-640).  The two alternate until every lane has reached its window's end: one marker per MCU row
-        // is one rule phase in ten windows, one per MCU a rule phase or two per window.  (Rounds 3-4 ran the C++ loops for the
-        // whole window of every restart stream: 64 x 1080p with DRI 120 138 against 182 Gpixel/s without.)
-        RestartCtx rc[NC];
-        uint32_t mnext[NC];
+    if (im.restart && !im.conformant) {
+        // Restart streams: the hand-written loop with the marker rule inside (sync_window_rst).  The lane brings the next two markers
+        // past its position, relative to the window; one that meets a third marker inside the window comes back early and is sent
+        // in again with the next two.
+        const uint32_t *mpos = P.mpos + im.mark_off;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            rc[c] = {P.mpos + im.mark_off, E.nmark, 0u, im.ri_blocks, 0u, im.conformant};
-            mnext[c] = 0xFFFFFFFFu;
-            if (!go[c]) continue;
-            if (mk[c] == 0xFFFFFFFFu) {
-                uint32_t lo = 0, hi = rc[c].nmark; // first marker past the state's position
+            if (go[c] && mk[c] == 0xFFFFFFFFu) {
+                uint32_t lo = 0, hi = E.nmark; // first marker past the state's position
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (rc[c].mpos[mid] <= p[c]) lo = mid + 1;
+                    if (mpos[mid] <= p[c]) lo = mid + 1;
                     else hi = mid;
                 }
                 mk[c] = lo;
             }
-            rc[c].mk = min(mk[c], rc[c].nmark);
-        }
-        for (;;) {
-            bool plain[NC], anyplain = false, anyleft = false;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                plain[c] = false;
-                if (go[c] && p[c] < pend[c]) {
-                    while (rc[c].mk < rc[c].nmark && rc[c].mpos[rc[c].mk] <= p[c]) rc[c].mk++;
-                    mnext[c] = rc[c].mk < rc[c].nmark ? rc[c].mpos[rc[c].mk] : 0xFFFFFFFFu;
-                    plain[c] = p[c] + 40u <= mnext[c];
-                    anyleft = true;
+            const uint32_t col = lds_addr(E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane);
+            bool left = go[c];
+            while (__any(left)) {
+                uint32_t mrel = 0x7FFFFFFFu, mrel2 = 0x7FFFFFFFu, prel = 0u;
+                SyncChain ch;
+                if (left) {
+                    while (mk[c] < E.nmark && mpos[mk[c]] <= p[c]) mk[c]++;
+                    if (mk[c] < E.nmark) mrel = min(mpos[mk[c]] - bit0[c], 0x7FFFFFF0u);
+                    if (mk[c] + 1u < E.nmark) mrel2 = min(mpos[mk[c] + 1u] - bit0[c], 0x7FFFFFF0u);
+                    prel = pend[c] - bit0[c];
                 }
-                anyplain = anyplain || plain[c];
-            }
-            if (!__any(anyleft)) break;
-            if (__any(anyplain)) {
-                SyncChain ch[NC];
-                uint32_t prel[NC];
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const uint32_t col = lds_addr(E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane);
-                    const uint32_t rel = plain[c] ? p[c] - bit0[c] : 0u;
-                    const uint4 me = lds_load<uint4>(E.mt4_addr + (plain[c] ? m[c] : 0u) * 16u);
-                    ch[c].p = rel;
-                    ch[c].z = plain[c] ? z[c] : 0u;
-                    ch[c].dcb = me.x;
-                    ch[c].acb = me.y;
-                    ch[c].mi = me.z;
-                    ch[c].nblk = 0u;
-                    ch[c].nrec = 0u;
-                    const uint32_t k0 = rel >> 5, o0 = rel & 31u;
-                    const uint32_t a = lds_load<uint32_t>(col + k0 * 256u), b = lds_load<uint32_t>(col + k0 * 256u + 256u);
-                    ch[c].hi = a;
-                    ch[c].lo = o0 ? b : a;
-                    ch[c].nxa = col + (k0 + (o0 ? 2u : 1u)) * 256u;
-                    ch[c].sh = (32u - o0) & 31u;
-                    // up to 39 bits before the marker, or the window's end (two-symbol steps stop 32 bits before either)
-                    prel[c] = plain[c] ? min(pend[c], mnext[c] - 39u) - bit0[c] : 0u;
-                }
-                sync_window<NC>(ch, prel, E.sec_addr);
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (plain[c]) {
-                        p[c] = bit0[c] + ch[c].p;
-                        z[c] = ch[c].z;
-                        m[c] = lds_load<uint4>(ch[c].mi).w;
-                        nblk[c] += ch[c].nblk;
-                        nrec[c] += ch[c].nrec;
-                    }
+                const uint32_t rel = left ? p[c] - bit0[c] : 0u;
+                const uint4 me = lds_load<uint4>(E.mt4_addr + (left ? m[c] : 0u) * 16u);
+                ch.p = rel;
+                ch.z = left ? z[c] : 0u;
+                ch.dcb = me.x;
+                ch.acb = me.y;
+                ch.mi = me.z;
+                ch.nblk = 0u;
+                ch.nrec = 0u;
+                const uint32_t k0 = rel >> 5, o0 = rel & 31u;
+                const uint32_t wa = lds_load<uint32_t>(col + k0 * 256u), wb = lds_load<uint32_t>(col + k0 * 256u + 256u);
+                ch.hi = wa;
+                ch.lo = o0 ? wb : wa;
+                ch.nxa = col + (k0 + (o0 ? 2u : 1u)) * 256u;
+                ch.sh = (32u - o0) & 31u;
+                uint32_t pstop = prel;
+                sync_window_rst(ch, pstop, mrel, mrel2, col, E.mt4_addr, E.sec_addr);
+                if (left) {
+                    p[c] = bit0[c] + ch.p;
+                    z[c] = ch.z;
+                    m[c] = lds_load<uint4>(ch.mi).w;
+                    nblk[c] += ch.nblk;
+                    nrec[c] += ch.nrec;
+                    left = p[c] < pend[c]; // stopped at a third marker: once more, with the markers after it
                 }
             }
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if (!(go[c] && p[c] < pend[c])) continue;
-                const uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
-                const uint32_t pair_lim = pend[c] > 32u ? pend[c] - 32u : 0u;
-                // runs while a marker is within reach (p + 40 > the next marker's position) and returns at the first step past that
-                sync_core<true>(E.L, col, bit0[c], E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p[c], z[c], m[c], pend[c], pair_lim, nblk[c], nrec[c], rc[c]);
+            if (go[c]) {
+                while (mk[c] < E.nmark && mpos[mk[c]] <= p[c]) mk[c]++;
             }
         }
+        return;
+    }
+    if (im.restart) { // conformant mode (never the default): the standard's interval rule, the C++ loops
 #pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (go[c]) mk[c] = rc[c].mk;
+        for (int c = 0; c < NC; c++) {
+            if (!go[c]) continue;
+            const uint32_t *col = E.s_stage + (uint32_t)c * (WPP + 2u) * 64u + lane;
+            RestartCtx rc = {P.mpos + im.mark_off, E.nmark, 0u, im.ri_blocks, 0u, im.conformant};
+            if (mk[c] == 0xFFFFFFFFu) {
+                uint32_t lo = 0, hi = rc.nmark; // first marker past the state's position
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rc.mpos[mid] <= p[c]) lo = mid + 1;
+                    else hi = mid;
+                }
+                mk[c] = lo;
+            }
+            rc.mk = min(mk[c], rc.nmark); // sync_span moves it past p
+            const uint32_t pair_lim = pend[c] > 32u ? pend[c] - 32u : 0u;
+            sync_span<true>(E.L, col, bit0[c], E.tabY, E.tabCb, E.tabCr, im.nby, im.nb, p[c], z[c], m[c], pend[c], pair_lim, nblk[c], nrec[c], rc);
+            mk[c] = rc.mk;
+        }
         return;
     }
     SyncChain ch[NC];

@@ -198,8 +198,7 @@ struct hjd_batch {
     // config 5) the whole of the second one's latency.
     struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, done = nullptr; };
     std::vector<SideStream> small_side; // per range (entry 0 also serves the single-range form)
-    hipStream_t seq_stream = nullptr;
-    hipEvent_t seq_fork = nullptr, seq_done = nullptr;
+    hipEvent_t seq_done = nullptr;    // recorded behind the emulation launches of a run (on the run's stream)
     bool seq_pending = false;
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, nwritewg_small = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
@@ -398,7 +397,7 @@ static int slab_reserve(hjd_batch *b, T *&p, size_t bytes)
 
 static void batch_free_device(hjd_batch *b)
 {
-    if (b->seq_stream) (void)hipStreamSynchronize(b->seq_stream); // a sequential emulation of the last run may still be at work on the slabs
+    if (b->seq_pending && b->seq_done) (void)hipEventSynchronize(b->seq_done); // the emulation of the last run may still be at work on the slabs
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     (void)hipFree(b->d_img);
     (void)hipFree(b->d_st);
@@ -427,8 +426,6 @@ static void batch_free_device(hjd_batch *b)
         if (ss.fork) (void)hipEventDestroy(ss.fork);
         if (ss.done) (void)hipEventDestroy(ss.done);
     }
-    if (b->seq_stream) (void)hipStreamDestroy(b->seq_stream);
-    if (b->seq_fork) (void)hipEventDestroy(b->seq_fork);
     if (b->seq_done) (void)hipEventDestroy(b->seq_done);
     (void)hipFree(b->d_chunk_mark);
     (void)hipFree(b->d_mpos);
@@ -1028,9 +1025,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 b->small_side.push_back(ss);
             }
         }
-        if (!b->rst_images.empty() && !b->seq_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&b->seq_stream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&b->seq_fork, hipEventDisableTiming));
+        if (!b->rst_images.empty() && !b->seq_done) {
             HIPCHK(hipEventCreateWithFlags(&b->seq_done, hipEventDisableTiming));
         }
         if (b->ranges.size() > 1) {
@@ -1338,25 +1333,22 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
 // launches of workgroups that return at once (config 5, clean: 0.5 % of the step).
 static int emulation_enqueue(hjd_batch *b, hipStream_t s)
 {
-    if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_stream) return HJD_OK;
-    HIPCHK(hipEventRecord(b->seq_fork, s));
-    HIPCHK(hipStreamWaitEvent(b->seq_stream, b->seq_fork, 0));
+    if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_done) return HJD_OK;
+    // On the run's own stream (round 5).  Rounds 3-4 put these launches on a side stream of the batch and joined it to the caller's
+    // stream before hjd_batch_run returned — serial either way, but a stream more per batch: four caller streams with restart
+    // streams in their batches were twelve streams on the process's four hardware queues, and a launch that shares a queue with
+    // another batch's synchronisation kernel waits for it (BASELINE config 5 on four caller streams: 87 Gpixel/s against 137 as one batch).
     // parallel over the resynchronisations where the image has node space; the one-lane kernel takes what that leaves
-    if (hjd_launch_seg_emulation(b->P, b->seq_stream)) return HJD_ERR_INTERNAL;
-    if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), b->seq_stream, b->P.nrst != 0u)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_seg_emulation(b->P, s)) return HJD_ERR_INTERNAL;
+    if (hjd_launch_seq_decode(b->P, 0u, (uint32_t)b->rst_images.size(), s, b->P.nrst != 0u)) return HJD_ERR_INTERNAL;
     {   // the back end again, over the candidates' workgroups only (round 3 launched the whole span from the first to the last
         // candidate: a batch with restart streams at both ends ran a million workgroups that returned at once)
         HjdParams P = b->P;
         P.gate_emulated = 1u;
-        if (hjd_launch_idct_color(P, b->nrst_groups, b->seq_stream)) return HJD_ERR_INTERNAL;
+        if (hjd_launch_idct_color(P, b->nrst_groups, s)) return HJD_ERR_INTERNAL;
     }
-    HIPCHK(hipEventRecord(b->seq_done, b->seq_stream));
+    HIPCHK(hipEventRecord(b->seq_done, s)); // a later run of this batch on ANOTHER stream, and a re-prepare, wait for it
     b->seq_pending = true;
-    // The caller's stream joins the side stream: whatever the caller enqueues after hjd_batch_run (its own kernels on the
-    // outputs, hjd_decode_batch_host's download) is ordered after the second back-end launch that rewrites the images the
-    // emulation decoded.  Free for batches without DRI (nothing is enqueued here at all); for clean restart streams the two
-    // launches return at once.
-    HIPCHK(hipStreamWaitEvent(s, b->seq_done, 0));
     return HJD_OK;
 }
 
