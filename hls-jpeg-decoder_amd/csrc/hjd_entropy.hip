@@ -132,7 +132,28 @@ struct RestartCtx {
     uint32_t ri_blocks;   // blocks per interval, 0 = no intervals expected
     uint32_t left;        // WRITE: blocks left in the current interval
     uint32_t conf;        // conformant mode (hjd_options.conformant): the standard's interval rule instead of the reference's
+    uint32_t mnext, mnext2; // WRITE: positions of markers mk and mk + 1 (all ones: none), kept a marker ahead so that a jump does not wait for a load
 };
+
+// WRITE: moves rc.mk to the first marker past p and leaves its position and the next one's in rc.mnext / rc.mnext2.  Four entries per
+// round trip (a lane starts from its subsequence's first marker — k_sync's submk — and a subsequence of a stream with a marker per
+// MCU holds a dozen: one dependent load each was 20 us of a lane's 30).
+__device__ __forceinline__ void marker_seek(RestartCtx &rc, uint32_t p)
+{
+    for (;;) {
+        uint32_t v[5];
+#pragma unroll
+        for (uint32_t q = 0; q < 5u; q++) v[q] = rc.mk + q < rc.nmark ? rc.mpos[rc.mk + q] : 0xFFFFFFFFu;
+        const uint32_t cnt = (v[0] <= p ? 1u : 0u) + (v[1] <= p ? 1u : 0u) + (v[2] <= p ? 1u : 0u) + (v[3] <= p ? 1u : 0u);
+        if (cnt < 4u) {
+            rc.mk += cnt;
+            rc.mnext = cnt == 0u ? v[0] : (cnt == 1u ? v[1] : (cnt == 2u ? v[2] : v[3]));
+            rc.mnext2 = cnt == 0u ? v[1] : (cnt == 1u ? v[2] : (cnt == 2u ? v[3] : v[4]));
+            return;
+        }
+        rc.mk += 4u;
+    }
+}
 
 // WRITE: where the outputs go.  A lane's records wait for their store in its column of an LDS ring (word k of the burst at
 // ring[k * HJD_WRITE_WG]): every lane's run of records starts at a multiple of HJD_REC_RUN, so a full burst is two aligned
@@ -306,7 +327,7 @@ __device__ __forceinline__ void sync_span(const EntropyLds &L, const uint32_t *_
 // record.  Everything a DC symbol does is predicated (selects) instead of branched: some lane of a wave is at a DC symbol, at
 // an end of block and at an AC coefficient in nearly every iteration, so every branch region is executed by every wave anyway
 // (round 2's loop: ~90 vector instructions per iteration, a third of them moves and mask juggling around the regions).
-template <bool RESTART, uint32_t WGSZ, uint32_t ENTCAP>
+template <bool RESTART, uint32_t WGSZ, uint32_t ENTCAP, bool WHOLE = false, bool CONF = false>
 __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *__restrict__ rowp, uint32_t stride, uint32_t row_bit0, uint32_t tabY,
                                            uint32_t tabCb, uint32_t tabCr, uint32_t nby, uint32_t nb, uint32_t &p, uint32_t &z, uint32_t &m,
                                            uint32_t end, uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags, RestartCtx &rc)
@@ -315,8 +336,8 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
     rd.init(rowp, p - row_bit0, stride);
     uint32_t mnext = 0xFFFFFFFFu;
     if (RESTART) {
-        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
-        mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+        if (!WHOLE) marker_seek(rc, p); // (WHOLE: write_span has just done it)
+        mnext = rc.mnext;
     }
     uint32_t pair = m < nby ? tabY : (m == nby ? tabCb : tabCr);
     uint32_t mnx = (m + 1u == nb) ? 0u : m + 1u;
@@ -324,7 +345,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
     uint32_t tb = z ? pair >> 16 : pair & 0xFFFFu;
     const char *lutb = reinterpret_cast<const char *>(L.lut);
 
-    while (p < end && (!RESTART || p + 40u > mnext)) {
+    while (p < end && (!RESTART || WHOLE || p + 40u > mnext)) { // WHOLE: the loop with the rules over the whole span (write_span)
         rd.prefetch();
         const uint32_t win = rd.window();
         uint32_t e = *reinterpret_cast<const uint16_t *>(lutb + tb + ((win >> (32 - HJD_LUT_BITS)) << 1));
@@ -351,7 +372,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
         // (W.tag = the block bits of the block in progress: set by the caller and at every block's end — computing it here on every
         // DC symbol was three instructions in every iteration)
         // the reference looks for a marker again between the DC code and its extra bits
-        if (RESTART && !rc.conf && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
+        if (RESTART && !CONF && isdc && s != 0u && p + len + 8u > mnext) flags |= HJD_FLAG_DIRTY;
         const uint32_t zw = z + adv - 1u;
         if (!isdc && s != 0u) { // AC run/size: loadjpg.cpp:776-808
             const uint32_t slot = W.slot_of[zw & 63u];
@@ -396,7 +417,7 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
             nxt = L.mt[mnx];
             tb = pair & 0xFFFFu;
         }
-        if (RESTART && rc.conf) {
+        if (RESTART && CONF) { // (a template parameter: as a run-time branch the two rule sets made the loop a third longer)
             // Conformant mode (never the default): ITU T.81 B.2.4.1 / F.1.2.3 — an interval ends where nothing but
             // padding (1-bits up to the byte boundary) separates the end of a block from the marker.
             bool jump = p > mnext;
@@ -413,7 +434,8 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 nxt = L.mt[mnx];
                 tb = pair & 0xFFFFu;
                 rc.mk++;
-                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                mnext = rc.mnext2;
+                rc.mnext2 = rc.mk + 1u < rc.nmark ? rc.mpos[rc.mk + 1u] : 0xFFFFFFFFu; // needed at the next jump only
                 if (p >= end) break;
                 rd.init(rowp, p - row_bit0, stride);
             }
@@ -437,7 +459,8 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 tb = pair & 0xFFFFu;
                 rc.left = rc.ri_blocks;
                 rc.mk++;
-                mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
+                mnext = rc.mnext2;
+                rc.mnext2 = rc.mk + 1u < rc.nmark ? rc.mpos[rc.mk + 1u] : 0xFFFFFFFFu; // needed at the next jump only
                 if (p >= end) break; // the next window is staged by the caller
                 rd.init(rowp, p - row_bit0, stride);
             } else if (blk_end && rc.ri_blocks != 0u && rc.left == 0u && nblk < W.nblocks) {
@@ -457,28 +480,35 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
         write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
         return;
     }
-    // see sync_span.  The plain loop keeps no count of the blocks left in the interval: it is brought up to date after it, and an
-    // interval that ended inside the stretch — no marker where the block count says one should be — is the same DIRTY
-    // verdict the loop with the rules gives (loadjpg.cpp:535-550 never fires there, the reference decodes on).
-    while (p < end && nblk < W.nblocks) {
-        while (rc.mk < rc.nmark && rc.mpos[rc.mk] <= p) rc.mk++;
-        const uint32_t mnext = rc.mk < rc.nmark ? rc.mpos[rc.mk] : 0xFFFFFFFFu;
-        if (p + 40u <= mnext) {
-            const uint32_t before = nblk;
-            write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, min(end, mnext - 39u), nblk, nrec, W, flags, rc);
-            const uint32_t done = nblk - before;
-            if (!rc.conf && rc.ri_blocks != 0u) {
-                if (done >= rc.left && before + rc.left < W.nblocks) {
-                    flags |= HJD_FLAG_DIRTY;
-                    rc.left = rc.ri_blocks - (done - rc.left) % rc.ri_blocks;
-                } else {
-                    rc.left -= done;
-                }
+    // A wave none of whose lanes meets a marker inside its span (nor comes within reach of one: a step is at most 31 bits, the rules
+    // look 8 bits ahead) runs the plain loop; any other wave runs the loop that knows the reference's rules (loadjpg.cpp:535-550,
+    // :631-640) over the whole span, ALL its lanes together.  (Rounds 2-4: the plain loop up to 39 bits before a lane's next marker,
+    // the loop with the rules around it, the plain loop again — the few lanes with a marker walked the rest of their span while the
+    // others of their wave waited: k_write 0.196 ms against 0.148 without DRI for 64 x 1080p with one marker per MCU row; round 2's
+    // first form ran the rules in every wave of every restart stream.)
+    marker_seek(rc, p);
+    const uint32_t mnext = rc.mnext;
+    const bool reach = p < end && nblk < W.nblocks && mnext < end + 40u;
+    if (!__any(reach)) {
+        // no marker in sight: the count of the blocks left in the interval is brought up to date afterwards, and an interval that ended
+        // inside the span — no marker where the block count says one should be — is the DIRTY verdict the loop with the rules gives
+        // (loadjpg.cpp:535-550 never fires there, the reference decodes on)
+        const uint32_t before = nblk;
+        write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        const uint32_t done = nblk - before;
+        if (!rc.conf && rc.ri_blocks != 0u) {
+            if (done >= rc.left && before + rc.left < W.nblocks) {
+                flags |= HJD_FLAG_DIRTY;
+                rc.left = rc.ri_blocks - (done - rc.left) % rc.ri_blocks;
+            } else {
+                rc.left -= done;
             }
-            if (p >= end || nblk >= W.nblocks) break;
         }
-        write_core<true, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        return;
     }
+    if (nblk >= W.nblocks) return;
+    if (rc.conf) write_core<true, WGSZ, ENTCAP, true, true>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+    else write_core<true, WGSZ, ENTCAP, true, false>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
 }
 
 // ---- stage 1: synchronisation ----------------------------------------------------------------
@@ -1172,6 +1202,23 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     for (uint32_t c = 0; c < C; c++) s_mark[sl[c]] = 0;
     if (tid == 0) s_wc[33] = 0u;
 
+    if (MODE != 0 && wg > 0u && P.rep_flags) {
+        // Repair launches (host re-synchronisation): the workgroups of an image form a CHAIN — workgroup w takes slot 0's start state
+        // from the last record of workgroup w - 1, so it waits until that one has left its final records (a flag per workgroup
+        // holding this launch's stamp; workgroups are dispatched in the order of their numbers, so the one waited for is running or
+        // done; bounded spin: a workgroup that gives up goes on with what is there, as before, and the host comes round again).
+        // One host round trip then carries a true state across ALL workgroup borders of an image — a uniform region spanning several
+        // synchronisation workgroups (an object on a black background under tables optimised for it: round 4 needed three round
+        // trips, one border each, 3.5 ms wall) — instead of one border per round trip.
+        if (tid == 0) {
+            const uint32_t want = (P.epoch << 2) | (uint32_t)MODE;
+            for (uint32_t spin = 0; spin < (1u << 20); spin++) {
+                if (__hip_atomic_load(&P.rep_flags[bid - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == want) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
     if (MODE == 0) {
         load_tables<true>(ts, s_lut, s_sec);
         __syncthreads();
@@ -1357,6 +1404,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
 #define HJD_RUN_D 96u // longest state period, in subsequences
 #endif
     bool elig[C], any_elig = false; // any_elig: some slot of this workgroup continues a run (ordinary content: none)
+    bool lastrep = false;
     uint32_t head[C], runq = 0;
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) {
@@ -1393,8 +1441,10 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         if (tid == 0) s_wc[32] = 0xFFFFFFFFu;
         __syncthreads();
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++)
+        for (uint32_t c = 0; c < C; c++) {
             if (myq[c]) atomicMin(&s_wc[32], myq[c]);
+            lastrep = lastrep || (myq[c] != 0u && row[c] + 1u == min(own1, nsub) && own1 < nsub); // the workgroup's last owned slot repeats an earlier one
+        }
         __syncthreads();
         runq = s_wc[32];
         unsigned long long nb0[C];
@@ -1422,6 +1472,67 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                     }
             }
         }
+    }
+
+    // A uniform region across a workgroup border (round 5).  The warm-up subsequences give a workgroup the true state at its first
+    // owned subsequence because a guessed decode falls into step with the true one — except on a periodic stream (a black or white
+    // background), where it may lock into a wrong cycle for good: the run rule above then hands the wrong states down the whole
+    // workgroup, k_write's check catches the border and the HOST re-synchronises (round 4: one round trip per run of such an image,
+    // 2-3 ms wall for an object on a black background under tables optimised for it).  Where every warm-up subsequence repeats the
+    // words of an earlier one (looking back beyond the workgroup's own rows) the workgroup instead WAITS for the workgroup before it
+    // — which publishes a flag when its own last subsequence continues a run — and takes slot 0's start state from that
+    // workgroup's final record, as a repair launch would.  Workgroups are dispatched in the order of their numbers, so the one waited
+    // for is running or done; the spin is bounded and a workgroup that gives up goes on from its guess, as before.  Ordinary content
+    // never waits and never publishes (its subsequences differ in their first words).
+    bool publish = false;
+    if (MODE == 0 && !SMALL && sib == 0u && !im.restart && P.sync_flags) {
+        bool uni = false; // this warm-up slot repeats an earlier subsequence
+        if (wv == 0u && lane < nwarm && wg > 0u) {
+            const uint32_t r = row0 + lane;
+            if (r > 0u && (r + 1u) * S <= total_bits) {
+                const uint32_t nwords = (S >> 5) + 2u;
+                const uint32_t *rw = row_base(E.wbase, r, P.log2_words);
+                for (uint32_t q = 1; q <= min(r, HJD_RUN_Q) && !uni; q++) {
+                    const uint32_t *rp = row_base(E.wbase, r - q, P.log2_words);
+                    bool same = rw[0] == rp[0];
+                    for (uint32_t k = 1; k < nwords && same; k++) same = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
+                    uni = same;
+                }
+            }
+        }
+        if (tid == 0) s_wc[34] = 0u, s_wc[35] = 0u;
+        __syncthreads();
+        if (wv == 0u) {
+            const unsigned long long bu = __ballot(uni);
+            if (lane == 0 && nwarm != 0u && wg > 0u && (uint32_t)__popcll(bu) == nwarm) s_wc[34] = 1u; // every warm-up slot: wait
+        }
+        // the last owned slot continues a run: the next workgroup may be waiting for this one's records
+        if (lastrep) s_wc[35] = 1u;
+        __syncthreads();
+        publish = s_wc[35] != 0u;
+        if (s_wc[34] != 0u) {
+            if (tid == 0) {
+                bool ok = false;
+                for (uint32_t spin = 0; spin < (1u << 16) && !ok; spin++) { // (40 ms at most)
+                    ok = __hip_atomic_load(&P.sync_flags[bid - 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == P.epoch;
+                    if (!ok) __builtin_amdgcn_s_sleep(32);
+                }
+                if (ok) {
+                    const uint4 pe = P.substate[im.sub0 + row0 - 1u];
+                    if (pe.x >= row0 * S && pe.x < row0 * S + 32u) { // a record's end always lies inside the next word
+                        s_wc[36] = pe.x;
+                        s_wc[37] = pe.y;
+                        s_wc[34] = 2u;
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_wc[34] == 2u) {
+                ext_p = s_wc[36];
+                ext_zm = s_wc[37];
+            }
+        }
+        __syncthreads();
     }
 
     uint32_t rounds = 0;
@@ -1788,18 +1899,29 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         }
         if (wg == 0 && tid == 0 && nsub == 0) atomicOr(&P.st[ii].flags, HJD_FLAG_SHORT); // a scan without a single data byte
     }
-    if (MODE != 0 && rounds == 0) return; // nothing to repair: the records stay as they are
+    if (!(MODE != 0 && rounds == 0)) { // (repair with nothing to repair: the records stay as they are)
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++)
-        if (owned[c]) {
-            const uint32_t s = sl[c], g = im.sub0 + row[c];
-            P.substate[g] = make_uint4(s_ep[s], (uint32_t)s_ezm[s], s_up[s], (uint32_t)s_uzm[s]);
-            P.subcnt[g] = s_cnt[s];
+        for (uint32_t c = 0; c < C; c++)
+            if (owned[c]) {
+                const uint32_t s = sl[c], g = im.sub0 + row[c];
+                P.substate[g] = make_uint4(s_ep[s], (uint32_t)s_ezm[s], s_up[s], (uint32_t)s_uzm[s]);
+                P.subcnt[g] = s_cnt[s];
+            }
+        if (tid == 0) { // diagnostics
+            atomicAdd(&P.st[ii].sync_decodes, ndec_total);
+            atomicAdd(&P.st[ii].sync_iters, rounds);
+            atomicMax(&P.st[ii].sync_iters_max, rounds);
         }
-    if (tid == 0) { // diagnostics
-        atomicAdd(&P.st[ii].sync_decodes, ndec_total);
-        atomicAdd(&P.st[ii].sync_iters, rounds);
-        atomicMax(&P.st[ii].sync_iters_max, rounds);
+    }
+    if (MODE == 0 && publish) { // the records of a workgroup whose last subsequences are a uniform run: the next one may be waiting for them
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&P.sync_flags[bid], P.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE != 0 && P.rep_flags) { // this workgroup's records are final for this launch: the next workgroup of the chain may go on
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&P.rep_flags[bid], (P.epoch << 2) | (uint32_t)MODE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -30,6 +30,8 @@ struct HjdParams {
     uint64_t tk_stride;
     uint32_t *tk_flags;        // [synchronisation workgroup][sibling]: the run (epoch) whose checkpoints are complete
     uint32_t tk_n, tk_nwg, epoch;
+    uint32_t *sync_flags;      // [large synchronisation workgroup]: the run (epoch) whose final records it has published (uniform regions across workgroup borders)
+    uint32_t *rep_flags;       // [repair workgroup]: stamp (epoch << 2 | mode) of the repair launch whose records it has left (a chain per image)
     uint2 *wgsum;              // per final-pass workgroup: blocks, records (padded runs)
     uint32_t *rec;             // AC coefficient records
     uint2 *blk;                // per block: first record index, DC difference as decoded (k_write)

@@ -219,6 +219,8 @@ struct hjd_batch {
     uint2 *d_ckpt = nullptr;
     uint2 *d_tkck = nullptr;        // sibling trajectories' checkpoints (small batches)
     uint32_t *d_tkflags = nullptr;
+    uint32_t *d_repflags = nullptr;  // repair workgroups' stamps (HjdParams::rep_flags)
+    uint32_t *d_syncflags = nullptr; // synchronisation workgroups' stamps (HjdParams::sync_flags)
     uint32_t *d_seqlist = nullptr;   // k_sync_seq: 64 device images per workgroup
     uint8_t *d_seg = nullptr;        // segment-parallel emulation: candidates, nodes, plans (one slab, carved up in batch_build)
     size_t seg_npos = 0, seg_nnodes = 0;
@@ -412,6 +414,8 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_ckpt);
     (void)hipFree(b->d_tkck);
     (void)hipFree(b->d_tkflags);
+    (void)hipFree(b->d_repflags);
+    (void)hipFree(b->d_syncflags);
     (void)hipFree(b->d_seqlist);
     (void)hipFree(b->d_seg);
     (void)hipFree(b->d_dbg);
@@ -764,6 +768,16 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
             }
         }
     }
+    {   // a fresh slab of repair stamps must not look like a launch's stamp (epochs start at 1)
+        const size_t before = b->cap[(const void *)&b->d_repflags];
+        need(slab_reserve(b, b->d_repflags, sizeof(uint32_t) * (b->nrepwg + 1)));
+        if (rcs == HJD_OK && b->cap[(const void *)&b->d_repflags] != before) HIPCHK(hipMemsetAsync(b->d_repflags, 0, b->cap[(const void *)&b->d_repflags], up));
+    }
+    {
+        const size_t before = b->cap[(const void *)&b->d_syncflags];
+        need(slab_reserve(b, b->d_syncflags, sizeof(uint32_t) * (b->nsyncwg + 1)));
+        if (rcs == HJD_OK && b->cap[(const void *)&b->d_syncflags] != before) HIPCHK(hipMemsetAsync(b->d_syncflags, 0, b->cap[(const void *)&b->d_syncflags], up));
+    }
     if (b->seg_nnodes) need(slab_reserve(b, b->d_seg, seg_slab_size(b)));
     need(slab_reserve(b, b->d_wgsum, sizeof(uint2) * (b->nwritewg + b->nwritewg_small)));
     need(slab_reserve(b, b->d_rec, sizeof(uint32_t) * (rec_cur + HJD_REC_RUN)));
@@ -893,6 +907,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
     P.ckpt = b->d_ckpt;
     P.tk_ckpt = b->d_tkck;
     P.tk_flags = b->d_tkflags;
+    P.rep_flags = b->d_repflags;
+    P.sync_flags = b->d_syncflags;
     P.nrst = b->seg_nnodes ? (uint32_t)b->rst_images.size() : 0u; // 0: no segment-parallel emulation in this batch
     P.seg_cut = 256u;
     if (d->seg_cut) P.seg_cut = 0x80000000u | d->seg_cut; // test switch: exactly this many (1: every chain meets a cut-off segment at once)

@@ -470,8 +470,9 @@ def test_uniform_frames(hjd):
         assert st == [0] * len(frames), (bits, st)
         for k in range(len(frames)):
             assert np.array_equal(b.download(k), want[k]), (bits, k)
-        if bits != 256:  # 1080p: one synchronisation workgroup per image at 2048 bits and more
-            assert b.resync_count() == 0, bits
+        assert b.resync_count() == 0, bits   # also at 256 bits, where a 1080p scan is several synchronisation workgroups: a workgroup whose warm-up
+                                             # subsequences are uniform waits for the one before it (round 5) instead of leaving the border to the host
+        if bits != 256:
             assert max(b.sync_stats(k)["iters_max"] for k in range(len(frames))) <= 16, [b.sync_stats(k) for k in range(len(frames))]
         b.close()
         d.close()
@@ -482,7 +483,7 @@ def test_flat_content_under_optimised_tables(hjd):
     code boundary and a guessed decode never falls into step with the true one — round 3 walked such a 4K frame with single lanes
     (24 / 13 / 5 / 9 ms of k_sync for the four frames below, 16-64 refinement rounds).  With the sibling trajectories of all 2 nb
     entering classes a slot entered at its first bit is adopted without decoding, and chain rounds run the truth down the
-    workgroup (sync_body: entry_adopt): bytes equal the oracle's, no host re-synchronisation, k_sync within 8 ms (measured: 2-5)."""
+    workgroup (sync_body: entry_adopt): bytes equal the oracle's, no host re-synchronisation, a bounded number of refinement rounds and decodes."""
     W, H = 3840, 2160
     rng = np.random.default_rng(3)
     patches = np.zeros((H, W, 3), np.uint8)
@@ -502,10 +503,35 @@ def test_flat_content_under_optimised_tables(hjd):
             b.run()
             assert b.finish() == [0] and b.resync_count() == 0, (name, hf, vf)
             assert np.array_equal(b.download(0), orgb), (name, hf, vf)
-            stages = dict(b.run_timed())
-            b.finish()
-            assert stages["huff_sync"] < 8.0, (name, hf, vf, stages, b.sync_stats(0))
+            # (no wall-clock bound in a parity test: the work is bounded instead — refinement rounds against the cap of 96, subsequence
+            # decodes against the scan's subsequences; times: profiles/r05_partly_uniform.txt)
+            stt = b.sync_stats(0)
+            assert stt["iters_max"] <= 64 and stt["decodes"] <= 3 * stt["nsub"], (name, hf, vf, stt)
             b.close()
+    # An object on a black background, 4:4:4, tables optimised for the image: the uniform region after the object spans
+    # a synchronisation workgroup's border, a guessed decode of a periodic stream locks into a wrong cycle and the warm-up
+    # subsequences cannot settle it — round 4 needed a host re-synchronisation for every run of this image.  The workgroup now waits
+    # for the one before it (sync_body: "a uniform region across a workgroup border"): no host round trip.
+    tex = T.synth_rgb(W, H, 11, 8.0)
+    obj = np.zeros((H, W, 3), np.uint8)
+    obj[H // 3:2 * H // 3, W // 8:W // 2] = tex[H // 3:2 * H // 3, W // 8:W // 2]
+    big_white = np.full((H, W, 3), 255, np.uint8)   # one uniform scan over several synchronisation workgroups at 256-bit subsequences
+    for name, rgb, hf, vf, mode, bits in (("object on black", obj, 1, 1, T.HUFF_FOUR_OPTIMISED, 0), ("object on black", obj, 2, 2, T.HUFF_FOUR_OPTIMISED, 0),
+                                          ("object on black", obj, 1, 1, T.HUFF_STD, 0), ("white", big_white, 2, 2, T.HUFF_STD, 256),
+                                          ("white", big_white, 1, 1, T.HUFF_FOUR_OPTIMISED, 512)):
+        j = T.encode_jpeg_ex(rgb, 85, hf, vf, huff_mode=mode)
+        orc, orgb, _, _, _ = T.oracle_decode(j)
+        assert orc == 0
+        dd = hjd.Decoder(0, subseq_bits=bits)
+        b = dd.prepare([j])
+        for _ in range(2):
+            b.run()
+            assert b.finish() == [0]
+        assert b.resync_count() == 0, (name, hf, vf, bits, b.sync_stats(0))
+        assert np.array_equal(b.download(0), orgb), (name, hf, vf, bits)
+        assert b.sync_stats(0)["iters_max"] <= 64
+        b.close()
+        dd.close()
     d.close()
 
 
