@@ -58,6 +58,7 @@
 #ifndef HJD_WRITE_WG
 #define HJD_WRITE_WG 256       // threads (= subsequences) per final-pass workgroup
 #endif
+#define HJD_SIB_LDS_EXTRA (HJD_SYNC_WG * 25u + 64u) // k_sync_sib: the end states of the siblings' trajectories per slot (2 bytes each), one byte of bookkeeping
 #define HJD_MAX_SIBLINGS 11u    // sibling trajectories per subsequence at most (k_sync_sib: small batches): 2 x 6 labels less the canonical one
 #define HJD_SEQ_MAX_BITS 65536u // scans up to this many bits go to k_sync_seq (one lane per image)
 #define HJD_WRITE_WG_SMALL 64   // lanes of the small final-pass workgroup (k_write_small: images with HjdImage::sync_small)

@@ -1154,6 +1154,15 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     // list is read into registers, behind a barrier, before a round's first window is staged.
     uint32_t *s_lp = s_rows;
     uint32_t *s_lst = s_rows + NS;
+    // k_sync_sib only (its LDS is HJD_SIB_LDS_EXTRA bytes larger), behind the staging windows: per slot the END state of every
+    // sibling's trajectory ([t] for slab t), packed into 16 bits (position past the slot's last bit, 5 bits | z << 5 | m << 11 |
+    // 1 << 15), and the slab a slot has adopted in this round (0: none).  With these a walk adopts a slot by LDS accesses alone — with
+    // the checkpoints in global memory every adopted slot was two or three dependent round trips, 10 us a slot for the one lane of
+    // a chain round — and the checkpoints are copied by all lanes at once after the round (materialise).
+    constexpr uint32_t NTRAJ = HJD_MAX_SIBLINGS + 1u; // 12
+    uint16_t *s_exit = reinterpret_cast<uint16_t *>(s_rows + (NS / 64u) * (P.phase_words + 2u) * 64u);
+    uint8_t *s_asg = reinterpret_cast<uint8_t *>(s_exit + NS * NTRAJ);
+    static_assert(HJD_SIB_LDS_EXTRA >= HJD_SYNC_WG * ((HJD_MAX_SIBLINGS + 1u) * 2u + 1u), "k_sync_sib's extra LDS");
     const HjdTableSet *ts = &P.tabs[im.tabset];
 
     RowEnv E;
@@ -1360,31 +1369,68 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     // down the workgroup — a few loads per adopted slot, a decode where a slot is entered otherwise — instead of every slot being
     // redone from its predecessor's stale state round after round, the truth moving on by one slot per round.  (A sweep over all
     // slots by one lane BEFORE the rounds did the same for flat content but cost ordinary and standard-table content 0.1-0.5 ms.)
-    auto can_adopt = [&](uint32_t s, uint32_t ap, uint32_t az, uint32_t am) -> bool {
-        if (!SIBS || im.restart || s < nwarm || ap != (row0 + s) * S || az > 1u) return false;
-        const uint32_t cls = az * im.nb + am; // 0: the canonical decode's own start state
-        return cls != 0u && cls <= TK && ((tk_ok >> (cls - 1u)) & 1u);
+    auto pack_state = [&](uint32_t pos, uint32_t base_bit, uint32_t zz, uint32_t mm) -> uint32_t { // 0 = none (not inside the next word)
+        return (pos >= base_bit && pos < base_bit + 32u) ? ((pos - base_bit) | (zz << 5) | (mm << 11) | 0x8000u) : 0u;
     };
-    auto entry_adopt = [&](uint32_t s, uint32_t &ap, uint32_t &az, uint32_t &am) -> bool {
-        if (!can_adopt(s, ap, az, am)) return false;
-        const uint32_t cls = az * im.nb + am;
-        uint2 last = make_uint2(0u, 0u);
-        uint32_t cn = 0;
-        for (uint32_t w = 0; w < nph; w++) {
-            last = *tkck(cls - 1u, w, s);
-            *ck(w, s) = last;
-            cn += ((last.y >> 9) & 2047u) | ((last.y >> 20) << 16);
+    auto adopt_slab = [&](uint32_t s, uint32_t ap, uint32_t az, uint32_t am) -> int { // the slab that holds slot s decoded from this state, or -1
+        if (!SIBS || im.restart || s < nwarm) return -1;
+        const uint32_t bit_s = (row0 + s) * S;
+        if (ap == bit_s && az <= 1u) {
+            const uint32_t cls = az * im.nb + am; // 0: the canonical decode's own start state
+            return (cls != 0u && cls <= TK && ((tk_ok >> (cls - 1u)) & 1u) && s_exit[s * NTRAJ + cls - 1u] != 0u) ? (int)cls - 1 : -1;
         }
+        return -1;
+    };
+    auto can_adopt = [&](uint32_t s, uint32_t ap, uint32_t az, uint32_t am) -> bool { return adopt_slab(s, ap, az, am) >= 0; };
+    auto entry_adopt = [&](uint32_t s, uint32_t &ap, uint32_t &az, uint32_t &am) -> bool {
+        const int t = adopt_slab(s, ap, az, am);
+        if (t < 0) return false;
+        const uint32_t e = s_exit[s * NTRAJ + (uint32_t)t];
         s_up[s] = ap;
         s_uzm[s] = (uint16_t)(az | (am << 8));
-        ap = last.x;
-        az = last.y & 63u;
-        am = (last.y >> 6) & 7u;
+        ap = (row0 + s + 1u) * S + (e & 31u);
+        az = (e >> 5) & 63u;
+        am = (e >> 11) & 7u;
         s_ep[s] = ap;
         s_ezm[s] = (uint16_t)(az | (am << 8));
-        s_cnt[s] = cn;
+        s_asg[s] = (uint8_t)(t + 1); // checkpoints and counts follow after the round (materialise)
         return true;
     };
+    // every lane: the slot's adopted trajectory becomes its own (checkpoints copied, counts added up)
+    auto materialise = [&]() {
+        if (!SIBS || TK == 0u) return;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t sm = sl[c], t = s_asg[sm];
+            if (t == 0u) continue;
+            uint32_t cn = 0;
+            for (uint32_t w = 0; w < nph; w++) {
+                const uint2 v = *tkck(t - 1u, w, sm);
+                *ck(w, sm) = v;
+                cn += ((v.y >> 9) & 2047u) | ((v.y >> 20) << 16);
+            }
+            s_cnt[sm] = cn;
+            s_asg[sm] = 0u;
+        }
+    };
+    if (SIBS) { // the siblings' end states (their slabs are complete: tk_ok)
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t sm = sl[c];
+            s_asg[sm] = 0u;
+            uint2 v[NTRAJ]; // all loads first: one round trip
+#pragma unroll
+            for (uint32_t t = 0; t < NTRAJ; t++) {
+                v[t] = make_uint2(0u, 0u);
+                if (t < TK && ((tk_ok >> t) & 1u) && valid[c] && sm >= nwarm) v[t] = *tkck(t, nph - 1u, sm);
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < NTRAJ; t++)
+                s_exit[sm * NTRAJ + t] = (uint16_t)((t < TK && ((tk_ok >> t) & 1u) && valid[c] && sm >= nwarm)
+                                                        ? pack_state(v[t].x, (row0 + sm + 1u) * S, v[t].y & 63u, (v[t].y >> 6) & 7u) : 0u);
+        }
+        __syncthreads();
+    }
     // Uniform regions.  Every MCU of a uniform image is the same few bits (4:2:0 with the standard tables: 32; with tables
     // optimised for the image 12 or less), so the stream is periodic, and on a periodic stream a guessed decode either falls into
     // step within a few symbols or locks into a wrong cycle for good, depending only on the bit phase it starts at (standard
@@ -1399,6 +1445,9 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
     //   runq : the distance q (one per workgroup: the smallest any slot found, 1 for a stream of one repeated word)
     //   elig : this slot's words equal those of the slot runq before it;  head : the nearest slot at or below that is not elig
     //   (the run's first runq slots end there).  Restart streams: their markers are not in the words; left to the ordinary rounds.
+#ifndef HJD_CHAIN_FROM
+#define HJD_CHAIN_FROM 3u // first refinement round that may be a chain round
+#endif
 #ifndef HJD_RUN_Q
 #define HJD_RUN_Q 32u // distances tried (the odd part of the MCU's bit length, in practice)
 #define HJD_RUN_D 96u // longest state period, in subsequences
@@ -1492,9 +1541,14 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             if (r > 0u && (r + 1u) * S <= total_bits) {
                 const uint32_t nwords = (S >> 5) + 2u;
                 const uint32_t *rw = row_base(E.wbase, r, P.log2_words);
-                for (uint32_t q = 1; q <= min(r, HJD_RUN_Q) && !uni; q++) {
+                const uint32_t w0 = rw[0], qn = min(r, HJD_RUN_Q);
+                uint32_t cm = 0; // distances at which the first word agrees (independent loads: one round trip; ordinary content: none)
+                for (uint32_t q = 1; q <= qn; q++) cm |= (row_base(E.wbase, r - q, P.log2_words)[0] == w0 ? 1u : 0u) << (q - 1u);
+                while (cm != 0u && !uni) {
+                    const uint32_t q = (uint32_t)__ffs((int)cm);
+                    cm &= cm - 1u;
                     const uint32_t *rp = row_base(E.wbase, r - q, P.log2_words);
-                    bool same = rw[0] == rp[0];
+                    bool same = true;
                     for (uint32_t k = 1; k < nwords && same; k++) same = rw[(size_t)k * 64u] == rp[(size_t)k * 64u];
                     uni = same;
                 }
@@ -1587,7 +1641,8 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             }
             __syncthreads(); // the flags have been read: s_lp is the work list again
         }
-        if (SIBS && tk_ok != 0u && !im.restart && rounds >= 3u) { // uniform
+        bool chain_round = false; // this round has ONE item (the first slot entered in a state it was not decoded from) whose walk runs down the workgroup
+        if (SIBS && tk_ok != 0u && !im.restart && rounds >= HJD_CHAIN_FROM) { // uniform
             // A chain round?  Three rounds have not settled the workgroup, many slots are still entered in a state they were not
             // decoded from, and most of those at their first bit in a sibling's start state: flat content (see entry_adopt).  Redoing
             // every such slot from its predecessor's stale end moves the truth on by one slot per round.  Instead only the FIRST of
@@ -1603,6 +1658,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
             }
             const uint32_t nd = (uint32_t)__syncthreads_count(dany ? 1 : 0), na = (uint32_t)__syncthreads_count(aany ? 1 : 0);
             if (nd >= 8u && na * 2u >= nd) {
+                chain_round = true;
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++) {
                     const unsigned long long bd = __ballot(dirty[c]);
@@ -1710,12 +1766,29 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                 if ((mk8 & 127u) != rounds + 1u) return true;
                 return (mk8 & 128u) != 0u && SIB && can_adopt(nx, ap, az, am);
             };
+            // Chain rounds (round 5): the one walk of the round does not END at a slot that was decoded from the very state it brings —
+            // that slot's records stand, the walk passes over it with its end state and goes on behind it.  (Round 4 ended the walk
+            // there and started the next round at the next slot entered in a wrong state: 17-42 rounds of a few slots each on the flat
+            // 4K frames, 70 us a round whatever it held.)
+            auto next_slot = [&](uint32_t nx, uint32_t &ap, uint32_t &az, uint32_t &am) -> uint32_t {
+                if (SIB && chain_round) {
+                    while (nx < NS && row0 + nx < lim && s_mark[nx] != (uint8_t)(rounds + 1u) && s_up[nx] == ap && (uint32_t)s_uzm[nx] == (az | (am << 8))) {
+                        ap = s_ep[nx];
+                        const uint32_t e = s_ezm[nx];
+                        az = e & 0xFFu;
+                        am = e >> 8;
+                        nx++;
+                    }
+                }
+                return nx;
+            };
             auto move_on = [&](int c) {
                 while (live[c]) {
                     uint32_t ap = p[c], az = z[c], am = m[c];
                     if (!entry_adopt(slot[c], ap, az, am)) break;
+                    const uint32_t nx = next_slot(slot[c] + 1u, ap, az, am);
                     p[c] = ap, z[c] = az, m[c] = am;
-                    const uint32_t ezm = az | (am << 8), nx = slot[c] + 1u;
+                    const uint32_t ezm = az | (am << 8);
                     live[c] = nx < NS && row0 + nx < lim && may_enter(nx, ap, az, am) && (s_up[nx] != ap || (uint32_t)s_uzm[nx] != ezm);
                     if (live[c]) {
                         s_mark[nx] = (uint8_t)(rounds + 1u);
@@ -1784,12 +1857,13 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                         s_ep[slot[c]] = p[c];
                         s_ezm[slot[c]] = (uint16_t)ezm;
                         s_cnt[slot[c]] = cn[c];
-                        const uint32_t nx = slot[c] + 1u;
-                        live[c] = nx < NS && row0 + nx < lim && may_enter(nx, p[c], z[c], m[c]) && (s_up[nx] != p[c] || (uint32_t)s_uzm[nx] != ezm);
+                        const uint32_t nx = next_slot(slot[c] + 1u, p[c], z[c], m[c]);
+                        const uint32_t ezm2 = z[c] | (m[c] << 8);
+                        live[c] = nx < NS && row0 + nx < lim && may_enter(nx, p[c], z[c], m[c]) && (s_up[nx] != p[c] || (uint32_t)s_uzm[nx] != ezm2);
                         if (live[c]) {
                             s_mark[nx] = (uint8_t)(rounds + 1u);
                             s_up[nx] = p[c];
-                            s_uzm[nx] = (uint16_t)ezm;
+                            s_uzm[nx] = (uint16_t)ezm2;
                             slot[c] = nx;
                             ph[c] = 0u;
                             cn[c] = 0u;
@@ -1802,7 +1876,7 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
                         s_ep[slot[c]] = p[c];
                         s_ezm[slot[c]] = (uint16_t)(z[c] | (m[c] << 8));
                         s_cnt[slot[c]] = cn[c];
-                        const uint32_t nx = slot[c] + 1u;
+                        const uint32_t nx = next_slot(slot[c] + 1u, p[c], z[c], m[c]);
                         live[c] = nx < NS && row0 + nx < lim && may_enter(nx, p[c], z[c], m[c]); // walk on: nobody else works on nx this round
                         if (live[c]) {
                             s_mark[nx] = (uint8_t)(rounds + 1u);
@@ -1828,6 +1902,10 @@ __device__ __forceinline__ void sync_body(const HjdParams &P)
         }
         stamp(0x10000 + steps_done); // wave 0's windows
         __syncthreads();
+        if (SIBS) {
+            materialise();
+            __syncthreads();
+        }
         stamp(0x20000);
     }
     {   // diagnostics: windows walked by all lanes -> subsequence decodes
@@ -2224,10 +2302,10 @@ int hjd_launch_sync(const HjdParams &P, uint32_t nwg, int mode, hipStream_t s)
     if (mode == 0) {
         if (set_dyn_lds(0, reinterpret_cast<const void *>(k_sync), P.lds_bytes_sync)) return -1;
         if (P.tk_n) {
-            if (set_dyn_lds(5, reinterpret_cast<const void *>(k_sync_sib), P.lds_bytes_sync)) return -1;
+            if (set_dyn_lds(5, reinterpret_cast<const void *>(k_sync_sib), P.lds_bytes_sync + HJD_SIB_LDS_EXTRA)) return -1;
             HjdParams Q = P;
             Q.tk_nwg = nwg; // the grid: tk_n sibling workgroups per synchronisation workgroup first, then the workgroups proper
-            hipLaunchKernelGGL(k_sync_sib, dim3(nwg * (P.tk_n + 1u)), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, Q);
+            hipLaunchKernelGGL(k_sync_sib, dim3(nwg * (P.tk_n + 1u)), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync + HJD_SIB_LDS_EXTRA, s, Q);
         } else {
             hipLaunchKernelGGL(k_sync, dim3(nwg), dim3(HJD_SYNC_THREADS), P.lds_bytes_sync, s, P);
         }

@@ -136,6 +136,13 @@ struct hjd_decoder {
     std::mutex conc_mu;
     hipEvent_t conc_ev[16] = {};
     uint64_t conc_runs = 0;
+    // The same for the back end and the final pass (HJD_IDCT_CONC / HJD_WRITE_CONC; 0 = no limit): two back-end kernels at a time each run
+    // at half speed and leave a stretch of the step in which none runs and the latency-bound kernels have the chip to themselves
+    // (tools/timeline.py on a kernel trace of the bench: no k_idct_color in flight 31 % of the time).  With a limit of one the
+    // runs' back ends follow each other in the order of the runs: a software pipeline across the caller's streams.
+    int idct_conc = 0, write_conc = 0;
+    hipEvent_t idct_ev[16] = {}, write_ev[16] = {};
+    uint64_t idct_runs = 0, write_runs = 0;
     uint32_t write_windows = 1; // staging windows one k_write lane decodes (HJD_WRITE_WINDOWS: tuning knob, power of two)
     int stagger = 0;           // ranges of a batch run as a software pipeline (batch_enqueue): 0 off, 1 after sync, 2 after the final pass
     int dirty_mode = 0;        // 0: restart streams outside the clean-resync domain are emulated sequentially; 1: refused
@@ -316,6 +323,8 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     if (const char *ew = getenv("HJD_WRITE_WINDOWS"))
         if (atoi(ew) >= 1 && atoi(ew) <= 64 && (atoi(ew) & (atoi(ew) - 1)) == 0) d->write_windows = (uint32_t)atoi(ew);
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
+    if (const char *ec = getenv("HJD_IDCT_CONC")) d->idct_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
+    if (const char *ec = getenv("HJD_WRITE_CONC")) d->write_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
     if (e && atoi(e) >= 64 && atoi(e) <= 16384 && (atoi(e) & (atoi(e) - 1)) == 0) {
@@ -361,6 +370,10 @@ extern "C" void hjd_decoder_destroy(hjd_decoder *d)
             if (sl.h_out) (void)hipHostFree(sl.h_out);
         }
         for (auto &e : d->conc_ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : d->idct_ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : d->write_ev)
             if (e) (void)hipEventDestroy(e);
         if (d->s_up) (void)hipStreamDestroy(d->s_up);
         if (d->s_run) (void)hipStreamDestroy(d->s_run);
@@ -1272,7 +1285,11 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         // the images with a small workgroup of their own: beside the large ones when the range holds both kinds.  The side stream
         // forks HERE, right behind the unstuff stage: the thumbnails' kernels do not wait for another run's k_sync (the waits
         // below concern the large synchronisation kernel only)
-        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && !names) ? &b->small_side[side] : nullptr;
+        // (a process has four hardware queues: a batch split into three or four ranges keeps its streams within them — the side streams
+        // of the last ranges are dropped, their small kernels follow the large one on the range's own stream; with eight streams for
+        // four ranges BASELINE config 5 ran at 80 Gpixel/s against 145 for two ranges)
+        const size_t nranges = b->ranges.size() > 1 ? b->ranges.size() : 1;
+        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && nranges + side < 5 && !names) ? &b->small_side[side] : nullptr;
         // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
         // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
         // joins before it
@@ -1324,8 +1341,23 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         if (hjd_launch_sync(P, r.nrepwg, 1, s)) return HJD_ERR_INTERNAL;
         if (hjd_launch_sync(P, r.nrepwg, 2, s)) return HJD_ERR_INTERNAL;
     }
+    // a stage's concurrency limit (see hjd_decoder::idct_conc): the k-th run's kernel waits for that of run k - limit
+    auto gate = [&](int limit, hipEvent_t *evs, uint64_t &runs, hipEvent_t &rec) -> int {
+        rec = nullptr;
+        if (limit <= 0 || b->dry || from_resync || names) return HJD_OK;
+        hjd_decoder *d = b->dec;
+        std::lock_guard<std::mutex> lk(d->conc_mu);
+        const uint64_t k = runs++;
+        if (!evs[k & 15] && hipEventCreateWithFlags(&evs[k & 15], hipEventDisableTiming) != hipSuccess) return HJD_ERR_INTERNAL;
+        if (k >= (uint64_t)limit && hipStreamWaitEvent(s, evs[(k - limit) & 15], 0) != hipSuccess) return HJD_ERR_INTERNAL;
+        rec = evs[k & 15];
+        return HJD_OK;
+    };
+    hipEvent_t wrec = nullptr, irec = nullptr;
     if ((rc = mark("huff_write"))) return rc;
+    if ((rc = gate(b->dec->write_conc, b->dec->write_ev, b->dec->write_runs, wrec))) return rc;
     if (hjd_launch_write(P, r.nwritewg, s)) return HJD_ERR_INTERNAL;
+    if (wrec && hipEventRecord(wrec, s) != hipSuccess) return HJD_ERR_INTERNAL;
     if (small_write_on_side) {
         if (hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return HJD_ERR_INTERNAL; // the side stream joins here
         joiner.ss = nullptr;
@@ -1336,7 +1368,9 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
     if ((rc = mark("dc_scan"))) return rc;
     if (hjd_launch_dcscan(P, r.ndc, s)) return HJD_ERR_INTERNAL;
     if ((rc = mark("idct_color"))) return rc;
+    if ((rc = gate(b->dec->idct_conc, b->dec->idct_ev, b->dec->idct_runs, irec))) return rc;
     if (hjd_launch_idct_color(P, r.ngroup, s)) return HJD_ERR_INTERNAL;
+    if (irec && hipEventRecord(irec, s) != hipSuccess) return HJD_ERR_INTERNAL;
     if ((rc = mark("end"))) return rc;
     if (nstage) *nstage = k;
     return HJD_OK;
