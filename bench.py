@@ -315,16 +315,18 @@ def main():
         for b, sh in zip(batches, streams):
             b.run(sh)
 
+    # Everything that is not a step happens BEFORE the warm-up steps — the stage events are created here and the warm-up runs use
+    # the first of them — so that between the last warm-up step and the first timed one lies a barrier and nothing else: with the
+    # statuses fetched and 340 events created in between, the timed region began on a GPU that had been idle for a millisecond
+    # or two (the first region of a run was 5 % below the following ones, with or without stage events).
+    timed_batches = [] if (args.internal_streams > 1 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
+    for b in timed_batches:
+        b.enable_timing(args.steps + args.warmup)
     for _ in range(args.warmup):
         step()
     barrier()
-    for b, sh in zip(batches, streams):
-        st = b.finish(sh)
-        assert all(s == 0 for s in st), st
-
-    timed_batches = [] if (args.internal_streams > 1 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
     for b in timed_batches:
-        b.enable_timing(args.steps)
+        b.collect_timing()  # the warm-up runs' intervals are dropped; the events are free for the timed steps
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -467,7 +469,10 @@ def main():
             if vi and iso.get(name):
                 # nominal issue cycles of this kernel's own instruction mix (profiles/valu_mix.json: 2 cycles per wave64
                 # instruction, 4 for packed fp32, 8 for transcendentals — costs the hardware cannot beat)
-                nom = sum(v.get("valu_insts_per_launch", 0) * mix.get("kernels", {}).get(v.get("kernel"), {}).get("nominal_cycles_per_inst", 2.0) for _, v in parts)
+                def nominal_of(kernel):  # the DYNAMIC mix where the executed fp32 counters exist (tools/valu_mix.py), else the static one
+                    m = mix.get("kernels", {}).get(kernel) or next((v2 for k2, v2 in mix.get("kernels", {}).items() if k2.split("<")[0] == kernel), {})
+                    return m.get("nominal_cycles_per_inst_dynamic", m.get("nominal_cycles_per_inst", 2.0))
+                nom = sum(v.get("valu_insts_per_launch", 0) * nominal_of(v.get("kernel")) for _, v in parts)
                 ent["valu_insts"] = vi
                 ent["cycles_per_valu_inst_per_simd_isolated"] = round(SIMD_CYC_PER_MS * iso[name] / vi, 2)
                 ent["valu_frac_of_nominal_issue"] = round(nom / (SIMD_CYC_PER_MS * iso[name]), 4)
@@ -493,7 +498,7 @@ def main():
             g = valu_step / (ms_step * 1e-3) / 1e9
             roof["valu"] = {"bound": "valu", "achieved": round(g, 1), "peak": VALU_PEAK_NOMINAL_GINST, "unit": "G wave-instr/s",
                             "frac": round(valu_nominal_cycles_step / (SIMD_CYC_PER_MS * ms_step), 4),
-                            "frac_meaning": "nominal issue cycles of the step's instructions (each kernel's own mix) / SIMD cycles of the step",
+                            "frac_meaning": "nominal issue cycles of the step's instructions (each kernel's own EXECUTED mix: packed fp32 from the SQ_INSTS_VALU_ADD/MUL_F32 counters) / SIMD cycles of the step",
                             "wave_insts_per_step": valu_step, "cycles_per_inst_per_simd": round(1024 * 2.4 / g, 2),
                             "cost_table_measured": "profiles/r02_valu_rate.txt", "mix": "profiles/valu_mix.json",
                             "counters": "profiles/sq_counters.json (stamp %s = the kernel sources running)" % src_hash,

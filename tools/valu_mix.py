@@ -54,7 +54,7 @@ def main():
     import hjdtools as T
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "valu_mix.json")
     so = os.path.join(ROOT, "hls-jpeg-decoder_amd", "lib", "libhjd.so")
-    res = {"kernel_src_sha16": T.kernel_src_hash(), "mix": "static (every instruction of the kernel body once)", "kernels": {}}
+    res = {"kernel_src_sha16": T.kernel_src_hash(), "mix": "static (every instruction of the kernel body once) and, where the executed fp32 counters exist, dynamic", "kernels": {}}
     with tempfile.TemporaryDirectory() as td:
         shutil.copy(so, td)
         subprocess.run([OBJDUMP, "--offloading", os.path.join(td, "libhjd.so")], check=True, capture_output=True)
@@ -79,9 +79,33 @@ def main():
                 t = line.strip().split()
                 if t and t[0].startswith("v_") and not t[0].startswith("v_mfma"):
                     res["kernels"][cur][classify(t[0])] += 1
+                    if re.match(r"v_(add|sub|subrev|mul)_f32", t[0]):
+                        res["kernels"][cur]["_scalar_f32_addmul"] += 1
+    # DYNAMIC mix (round 5): profiles/sq_counters.json now carries, per kernel, the EXECUTED fp32 add and multiply
+    # instructions (SQ_INSTS_VALU_ADD_F32 / _MUL_F32, a third PMC pass).  Of those the packed share is taken from the ISA (packed
+    # against scalar fp32 add / mul instructions of the kernel): executed packed = (ADD_F32 + MUL_F32) x that share, each priced at
+    # 4 cycles, everything else at 2.  The static average stays in the file for comparison; bench.py uses the dynamic one.
+    dyn = {}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+        if sq.get("kernel_src_sha16") == res["kernel_src_sha16"]:
+            for st in sq.get("stages", {}).values():
+                c = st.get("counters", {})
+                if "SQ_INSTS_VALU_ADD_F32" in c and c.get("SQ_INSTS_VALU"):
+                    dyn[st["kernel"]] = (c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"], c["SQ_INSTS_VALU"])
+    except Exception:
+        pass
     for k, c in list(res["kernels"].items()):
+        scalar = c.pop("_scalar_f32_addmul", 0)
         n = sum(c.values())
-        res["kernels"][k] = {"valu_static": n, "by_class": dict(sorted(c.items())),
+        ent_dyn = {}
+        if k in dyn or k.split("<")[0] in dyn:
+            fp, tot = dyn.get(k, dyn.get(k.split("<")[0]))
+            share = c.get("packed_f32", 0) / max(1, c.get("packed_f32", 0) + scalar)
+            packed_exec = fp * share
+            ent_dyn = {"executed_fp32_addmul_per_valu": round(fp / tot, 4), "packed_share_of_fp32_addmul_static": round(share, 4),
+                       "nominal_cycles_per_inst_dynamic": round((2.0 * (tot - packed_exec) + 4.0 * packed_exec) / tot, 3)}
+        res["kernels"][k] = {"valu_static": n, "by_class": dict(sorted(c.items())), **ent_dyn,
                              "nominal_cycles_per_inst": round(sum(NOMINAL[x] * v for x, v in c.items()) / max(n, 1), 3),
                              "measured_cycles_per_inst": round(sum(MEASURED[x] * v for x, v in c.items()) / max(n, 1), 3)}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
