@@ -269,6 +269,18 @@ def main():
     src_ids = sorted({g % n_src for g in mine})
     if args.internal_streams > 1:
         args.streams = 1
+    # The caller streams FIRST, before the library creates any of its own: the HIP runtime gives the first four streams of a process
+    # (the default stream and the next three) a hardware queue each and lets every later one share the least used — two caller
+    # streams that share a queue run one behind the other (round 5, rocprofv3 Queue_Id: four fresh streams created after the
+    # decoder sat on three queues, 288 Gpixel/s against 323; BASELINE config 5: 131 against 169).  INTEGRATION.md §streams.
+    ns = max(1, min(args.streams, len(mine)))
+    torch.zeros(1, device="cuda:%d" % local_rank)  # the default stream's hardware queue exists before any other stream is created
+    torch.cuda.synchronize()
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    for ts in tstreams:  # ... and USED once: the runtime binds a stream to its hardware queue at the stream's first command
+        with torch.cuda.stream(ts):
+            torch.zeros(1, device="cuda:%d" % local_rank)
+    torch.cuda.synchronize()
     dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=max(1, args.internal_streams))  # 1 = no split inside the library
     if args.content == "photo":
         import numpy as np
@@ -300,7 +312,6 @@ def main():
         assert all(s == 0 for s in b.parse_status), b.parse_status
     tot = [b.totals() for b in batches]
     pixels, alg_bytes, scan_bytes = (sum(t[k] for t in tot) for k in range(3))
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
     streams = [ts.cuda_stream for ts in tstreams]
 
     def barrier():

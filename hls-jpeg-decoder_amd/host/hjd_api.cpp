@@ -141,6 +141,9 @@ struct hjd_decoder {
     // (tools/timeline.py on a kernel trace of the bench: no k_idct_color in flight 31 % of the time).  With a limit of one the
     // runs' back ends follow each other in the order of the runs: a software pipeline across the caller's streams.
     int idct_conc = 0, write_conc = 0;
+    int no_side = 0;           // experiment knob HJD_NO_SIDE: the small images' kernels follow the large ones on the run's own stream
+    void *recent_streams[8] = {}; // the streams of the last eight runs (conc_mu): how many caller streams are in flight
+    uint64_t recent_n = 0;
     hipEvent_t idct_ev[16] = {}, write_ev[16] = {};
     uint64_t idct_runs = 0, write_runs = 0;
     uint32_t write_windows = 1; // staging windows one k_write lane decodes (HJD_WRITE_WINDOWS: tuning knob, power of two)
@@ -207,6 +210,9 @@ struct hjd_batch {
     std::vector<SideStream> small_side; // per range (entry 0 also serves the single-range form)
     hipEvent_t seq_done = nullptr;    // recorded behind the emulation launches of a run (on the run's stream)
     bool seq_pending = false;
+    bool emulate_in_run = false;      // a finish of these contents found restart streams to emulate: later runs enqueue the emulation themselves
+    bool emul_enqueued = false;       // the last enqueue of this batch carried the emulation launches
+    int callers_seen = 1;             // distinct streams among the decoder's last eight runs, as of this batch's last enqueue
     uint32_t nchunks = 0, nsub = 0, nsyncwg = 0, nsyncwg_small = 0, nrepwg = 0, nwritewg = 0, nwritewg_small = 0, ngroups = 0, ndcchunks = 0;
     uint32_t *d_dcsum = nullptr;
     uint32_t nmarks = 0;
@@ -324,6 +330,7 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
         if (atoi(ew) >= 1 && atoi(ew) <= 64 && (atoi(ew) & (atoi(ew) - 1)) == 0) d->write_windows = (uint32_t)atoi(ew);
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *ec = getenv("HJD_IDCT_CONC")) d->idct_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
+    d->no_side = getenv("HJD_NO_SIDE") != nullptr;
     if (const char *ec = getenv("HJD_WRITE_CONC")) d->write_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
@@ -706,6 +713,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         b->seg_nnodes = node_cur;
     }
     b->seq_pending = false;
+    b->emulate_in_run = false; // new contents
+    b->emul_enqueued = false;
     b->raw_bytes = raw_cur;
     b->ustream_bytes = us_cur;
     b->nblk_entries = blk_cur;
@@ -1287,9 +1296,10 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         // below concern the large synchronisation kernel only)
         // (a process has four hardware queues: a batch split into three or four ranges keeps its streams within them — the side streams
         // of the last ranges are dropped, their small kernels follow the large one on the range's own stream; with eight streams for
-        // four ranges BASELINE config 5 ran at 80 Gpixel/s against 145 for two ranges)
+        // four ranges BASELINE config 5 ran at 80 Gpixel/s against 145 for two ranges; and none at all when the decoder's recent runs
+        // came on three or more caller streams: those runs overlap one another, a side stream each only adds queues to share)
         const size_t nranges = b->ranges.size() > 1 ? b->ranges.size() : 1;
-        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && nranges + side < 5 && !names) ? &b->small_side[side] : nullptr;
+        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && nranges + side < 5 && !names && !b->dec->no_side && b->callers_seen < 3) ? &b->small_side[side] : nullptr;
         // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
         // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
         // joins before it
@@ -1381,9 +1391,17 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
 // one-lane kernel for what those leave), then the back end once more for exactly those images — on the batch's side stream,
 // which waits for the run.  All launches are gated on the device: for a batch whose restart streams are all clean they are six
 // launches of workgroups that return at once (config 5, clean: 0.5 % of the step).
-static int emulation_enqueue(hjd_batch *b, hipStream_t s)
+static int emulation_enqueue(hjd_batch *b, hipStream_t s, bool force = false)
 {
+    b->emul_enqueued = false;
     if (b->rst_images.empty() || b->dec->dirty_mode != 0 || !b->seq_done) return HJD_OK;
+    // Not before a run of this batch has been seen to need them (hjd_batch_finish, which then enqueues them itself and sets
+    // emulate_in_run for the later runs of the same contents): the six launches are gated on the device and return at once for
+    // clean restart streams, but they are six dependent launches at the end of every run, and with several caller streams in
+    // flight the command processor let a run start only when the run two before it (another stream's) had got through them —
+    // BASELINE config 5, clean, on four caller streams: 148 Gpixel/s with them, 167-176 without (round 5; which of the six made
+    // no difference, their number did).
+    if (!force && !b->emulate_in_run) return HJD_OK;
     // On the run's own stream (round 5).  Rounds 3-4 put these launches on a side stream of the batch and joined it to the caller's
     // stream before hjd_batch_run returned — serial either way, but a stream more per batch: four caller streams with restart
     // streams in their batches were twelve streams on the process's four hardware queues, and a launch that shares a queue with
@@ -1398,6 +1416,7 @@ static int emulation_enqueue(hjd_batch *b, hipStream_t s)
         if (hjd_launch_idct_color(P, b->nrst_groups, s)) return HJD_ERR_INTERNAL;
     }
     HIPCHK(hipEventRecord(b->seq_done, s)); // a later run of this batch on ANOTHER stream, and a re-prepare, wait for it
+    b->emul_enqueued = true;
     b->seq_pending = true;
     return HJD_OK;
 }
@@ -1417,6 +1436,19 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     // is through (other batches are not held up)
     if (b->seq_pending) HIPCHK(hipStreamWaitEvent(s, b->seq_done, 0));
     b->P.epoch = ++b->epoch; // what this run's sibling workgroups write into their flags (never 0)
+    if (!from_resync) {
+        hjd_decoder *d = b->dec;
+        std::lock_guard<std::mutex> lk(d->conc_mu);
+        d->recent_streams[d->recent_n++ & 7u] = (void *)s;
+        const int n = (int)(d->recent_n < 8u ? d->recent_n : 8u);
+        int distinct = 0;
+        for (int i = 0; i < n; i++) {
+            bool seen = false;
+            for (int j = 0; j < i; j++) seen |= d->recent_streams[j] == d->recent_streams[i];
+            distinct += seen ? 0 : 1;
+        }
+        b->callers_seen = distinct;
+    }
     if (b->epoch == 0xFFFFFFFFu) b->epoch = 0;
     if (names || b->ranges.size() <= 1) {
         hjd_batch::Range all{};
@@ -1563,7 +1595,19 @@ extern "C" int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status)
             HIPCHK(hipMemcpy(b->state.data(), b->d_st, sizeof(HjdImageState) * b->nimg, hipMemcpyDeviceToHost));
             bool stale = false;
             for (auto &st : b->state) stale |= (st.flags & HJD_FLAG_NOT_CONVERGED) != 0;
-            if (!stale) break;
+            if (!stale) {
+                // restart streams the parallel path flagged and no emulation has looked at yet: the first run of these contents
+                // does not carry the emulation launches (emulation_enqueue) — they follow here, and the later runs enqueue them
+                bool need = false;
+                if (b->dec->dirty_mode == 0 && !b->emul_enqueued)
+                    for (uint32_t q : b->rst_images) need |= (b->state[q].flags & (HJD_FLAG_DIRTY | HJD_FLAG_BAD_MARKER)) && !b->state[q].emulated;
+                if (!need) break;
+                attempt--; // not a re-synchronisation
+                b->emulate_in_run = true;
+                int rc = emulation_enqueue(b, s, true);
+                if (rc) return rc;
+                continue;
+            }
             if (b->dec->verbose)
                 for (size_t k = 0; k < b->state.size(); k++)
                     if (b->state[k].flags & HJD_FLAG_NOT_CONVERGED)

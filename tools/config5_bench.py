@@ -18,6 +18,10 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# --hw-queues N: the HIP runtime's GPU_MAX_HW_QUEUES (default 4 per process), set before the runtime loads.  Four caller streams
+# beside the library's own want more than four hardware queues: streams that share one run one behind the other.
+if "--hw-queues" in sys.argv:
+    os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[sys.argv.index("--hw-queues") + 1]
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np  # noqa: E402
@@ -37,6 +41,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--dirty-mode", type=int, default=0, help="1: restart streams outside the clean-resync domain are refused (no emulation launches)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: the runtime's default, 4)")
+    ap.add_argument("--images", type=int, default=128, help="batch size (a multiple of 32: the 32 distinct images repeated)")
     a = ap.parse_args()
     sizes = [(3840, 2160), (1920, 1080), (1280, 720), (1000, 700), (777, 333), (640, 480), (512, 512), (250, 187)]
     samp = [(1, 1), (2, 1), (2, 2), (1, 1), (2, 1), (2, 2), (1, 2), (4, 1)]
@@ -51,17 +58,24 @@ def main():
         # the smooth-chroma image 27 needs sigma 12 for that (--hostile keeps sigma 7 everywhere)
         specs.append((w, h, 9000 + k, 85, hf, vf, rst, 12.0 if (rst == 16 and not a.hostile) else 7.0))
     src = [T.synth_jpeg(*s) for s in specs]
-    N = 128
+    N = max(32, a.images // 32 * 32)
     jpgs = [src[k % 32] for k in range(N)]
     px = [specs[k % 32][0] * specs[k % 32][1] for k in range(N)]
     pixels = sum(px)
     ns = max(1, a.caller_streams)
     parts = shard.partition(px, ns)  # by cost, as the ranks of a node are dealt their shards
-    dec = hjd.Decoder(0, streams=a.internal_streams)
+    # the caller streams before the library creates any of its own: a hardware queue each (bench.py)
+    torch.zeros(1, device="cuda:0")  # the default stream's hardware queue exists before any other stream is created
+    torch.cuda.synchronize()
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(1, a.caller_streams) - 1)]
+    for ts in tstreams:  # ... and USED once: the runtime binds a stream to its hardware queue at the stream's first command
+        with torch.cuda.stream(ts):
+            torch.zeros(1, device="cuda:0")
+    torch.cuda.synchronize()
+    dec = hjd.Decoder(0, streams=a.internal_streams, dirty_mode=a.dirty_mode)
     batches = [dec.prepare([jpgs[i] for i in p]) for p in parts]
     for b in batches:
         assert all(s == 0 for s in b.parse_status)
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
     streams = [t.cuda_stream for t in tstreams]
 
     def step():
@@ -135,11 +149,11 @@ def main():
     dom = max(((n, v) for n, v in ovl.items() if n != "sync_wait"), key=lambda x: x[1]) if ovl else max(iso.items(), key=lambda x: x[1])
     launch_alg = alg / ns
     out = {"metric": "Mpixels/s JPEG->RGB",
-           "config": {"workload": "BASELINE config 5: 128 images, 8 sizes 3840x2160..250x187, 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1, half of them with "
+           "config": {"workload": "BASELINE config 5: %d images, 8 sizes 3840x2160..250x187, 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1, half of them with "
                                   "DRI (intervals of %s), resident in HBM, RGB to HBM; partitioned by pixel count into %d batch(es), one HIP stream each"
-                                  % ("one MCU row, four rows, 7 MCUs, 1 MCU" if a.hostile else "one MCU row, four rows, two rows, 16 MCUs", ns),
-                      "images": N, "distinct_images": 32, "caller_streams": ns, "internal_streams": a.internal_streams,
-                      "with_dri": sum(1 for s in specs if s[6]) * 4, "scan_bytes": scan, "algorithmic_bytes": alg},
+                                  % (N, "one MCU row, four rows, 7 MCUs, 1 MCU" if a.hostile else "one MCU row, four rows, two rows, 16 MCUs", ns),
+                      "images": N, "distinct_images": 32, "caller_streams": ns, "internal_streams": a.internal_streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
+                      "with_dri": sum(1 for s in specs if s[6]) * (N // 32), "scan_bytes": scan, "algorithmic_bytes": alg},
            "value": round(pixels / dt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 4), "steps": a.steps,
            "spread": [round(pixels / x / 1e6, 1) for x in spread],
            "stage_ms_overlapped": ovl, "stage_ms_isolated": {k: round(v, 4) for k, v in iso.items()},

@@ -14,10 +14,12 @@ import sys
 def main():
     d = sys.argv[1]
     rows = []
+    qmap = {}
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = re.sub(r"<.*", "", r["Kernel_Name"].split("(")[0].replace("void ", "")).strip()
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Stream_Id", r.get("Queue_Id", "0"))))
+            qmap.setdefault(r.get("Stream_Id", "?"), collections.Counter())[(r.get("Queue_Id", "?"), k)] += 1
     rows.sort()
     if not rows:
         print("no kernel trace found")
@@ -47,6 +49,15 @@ def main():
         active[k] += dlt
         t_prev = t
     print("window %.3f ms, %d launches" % (span / 1e6, len(sel)))
+    for st in sorted(qmap):  # HIP stream -> hardware queue(s), with the kernels launched there
+        byq = collections.defaultdict(list)
+        for (q, k), n in qmap[st].items():
+            byq[q].append("%s x%d" % (k, n))
+        for q in sorted(byq):
+            print("  stream %s -> queue %s: %s" % (st, q, ", ".join(sorted(byq[q])[:6])))
+    if len(sys.argv) > 2:  # the first N launches of the window, one per line: start and duration in us, kernel, queue
+        for s0, e0, k, q in sel[:int(sys.argv[2])]:
+            print("    %9.1f  %8.1f  %-18s q%s" % ((s0 - lo) / 1e3, (e0 - s0) / 1e3, k, q))
     for k, v in busy.most_common():
         dur = [e - s for s, e, kk, q in sel if kk == k]
         print("  %-18s running %5.1f %% of the time; %4d launches, mean %.4f ms" % (k, 100.0 * v / span, len(dur), sum(dur) / len(dur) / 1e6))
