@@ -143,6 +143,15 @@ struct hjd_decoder {
     int idct_conc = 0, write_conc = 0;
     int no_side = 0;           // experiment knob HJD_NO_SIDE: the small images' kernels follow the large ones on the run's own stream
     void *recent_streams[8] = {}; // the streams of the last eight runs (conc_mu): how many caller streams are in flight
+    // The library's own streams: three per decoder, created AND used once when the decoder is created.  The HIP runtime binds a
+    // stream to one of the process's hardware queues (four by default, GPU_MAX_HW_QUEUES) at its first command — a new queue while
+    // there are fewer than four, the least shared one afterwards — and two streams on one queue run one behind the other.  A decoder
+    // created early in the process therefore holds queues of its own for the ranges of a split batch (ranges 1..3; range 0 runs on
+    // the caller's stream) and for the small images' side streams.  Until round 5 every batch created its own: the ranges of one
+    // batch shared queues with one another and with the caller's stream (rocprofv3 Queue_Id; BASELINE config 5 split four ways
+    // inside the library: 119 Gpixel/s against 147 unsplit).
+    hipStream_t lib_streams[3] = {};
+    void *d_bind = nullptr;
     uint64_t recent_n = 0;
     hipEvent_t idct_ev[16] = {}, write_ev[16] = {};
     uint64_t idct_runs = 0, write_runs = 0;
@@ -359,6 +368,22 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
             d->overlap_auto = false;
         }
     }
+    {
+        DeviceGuard g(device);
+        bool ok = g.ok && hipMalloc(&d->d_bind, 256) == hipSuccess;
+        for (auto &st : d->lib_streams) {
+            ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipMemsetAsync(d->d_bind, 0, 256, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess; // bound to a queue
+        }
+        if (!ok) {
+            for (auto &st : d->lib_streams)
+                if (st) (void)hipStreamDestroy(st);
+            (void)hipFree(d->d_bind);
+            delete d;
+            hjd_set_last_status(HJD_ERR_NO_DEVICE);
+            return nullptr;
+        }
+    }
     return d;
 }
 
@@ -382,6 +407,9 @@ extern "C" void hjd_decoder_destroy(hjd_decoder *d)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : d->write_ev)
             if (e) (void)hipEventDestroy(e);
+        for (auto &st : d->lib_streams)
+            if (st) (void)hipStreamDestroy(st);
+        (void)hipFree(d->d_bind);
         if (d->s_up) (void)hipStreamDestroy(d->s_up);
         if (d->s_run) (void)hipStreamDestroy(d->s_run);
         if (d->s_down) (void)hipStreamDestroy(d->s_down);
@@ -445,8 +473,7 @@ static void batch_free_device(hjd_batch *b)
     (void)hipFree(b->d_dca);
     (void)hipFree(b->d_maps);
     (void)hipFree(b->d_dcsum);
-    for (auto &ss : b->small_side) {
-        if (ss.st) (void)hipStreamDestroy(ss.st);
+    for (auto &ss : b->small_side) { // (ss.st belongs to the decoder)
         if (ss.fork) (void)hipEventDestroy(ss.fork);
         if (ss.done) (void)hipEventDestroy(ss.done);
     }
@@ -458,8 +485,8 @@ static void batch_free_device(hjd_batch *b)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
         for (auto &e : v) (void)hipEventDestroy(e);
-    for (auto &st : b->istreams)
-        if (st) (void)hipStreamDestroy(st);
+    for (size_t k = 4; k < b->istreams.size(); k++) // (1..3 belong to the decoder)
+        if (b->istreams[k]) (void)hipStreamDestroy(b->istreams[k]);
     for (auto &e : b->join_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : b->stagger_ev)
@@ -1057,11 +1084,16 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         if (side_needed) {
             while (b->small_side.size() < b->ranges.size()) {
                 hjd_batch::SideStream ss;
-                HIPCHK(hipStreamCreateWithFlags(&ss.st, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
                 b->small_side.push_back(ss);
             }
+        }
+        // the decoder's three streams: ranges 1..3 first, what is left to the side streams of ranges 0, 1, ... (none: that range's
+        // small kernels follow its large one on the range's own stream) — a batch and the caller's stream stay within four queues
+        for (size_t k = 0; k < b->small_side.size(); k++) {
+            const size_t nr = b->ranges.size() > 1 ? b->ranges.size() : 1, idx = nr - 1 + k;
+            b->small_side[k].st = idx < 3 ? b->dec->lib_streams[idx] : nullptr;
         }
         if (!b->rst_images.empty() && !b->seq_done) {
             HIPCHK(hipEventCreateWithFlags(&b->seq_done, hipEventDisableTiming));
@@ -1071,7 +1103,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
                 hipStream_t st = nullptr; // entry 0 stays empty: range 0 runs on the caller's stream
                 hipEvent_t e = nullptr;
                 if (!b->istreams.empty()) {
-                    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    if (b->istreams.size() <= 3) st = b->dec->lib_streams[b->istreams.size() - 1];
+                    else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); // more than four ranges: streams of the batch's own
                     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 }
                 b->istreams.push_back(st);
@@ -1298,8 +1331,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         // of the last ranges are dropped, their small kernels follow the large one on the range's own stream; with eight streams for
         // four ranges BASELINE config 5 ran at 80 Gpixel/s against 145 for two ranges; and none at all when the decoder's recent runs
         // came on three or more caller streams: those runs overlap one another, a side stream each only adds queues to share)
-        const size_t nranges = b->ranges.size() > 1 ? b->ranges.size() : 1;
-        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && nranges + side < 5 && !names && !b->dec->no_side && b->callers_seen < 3) ? &b->small_side[side] : nullptr;
+        hjd_batch::SideStream *ss = ((r.nssyncwg || r.nseq) && r.nsyncwg && side < b->small_side.size() && b->small_side[side].st && !names && !b->dec->no_side && b->callers_seen < 3) ? &b->small_side[side] : nullptr;
         // the small images' final pass follows their synchronisation on the side stream — unless the large final pass needs what
         // the side stream computes (an image synchronised by a small kernel but written by the large one): then the side stream
         // joins before it

@@ -159,10 +159,14 @@ void hjd_batch_destroy(hjd_batch *b);
 hjd_batch *hjd_batch_prepare_parsed(hjd_decoder *d, int n, const hjd_jpeg_data *jdata, int out_format, int *status);
 
 /* Enqueue the whole decode (all kernels) on `hip_stream` (a hipStream_t, may be NULL = default
- * stream).  Asynchronous; inputs and outputs stay in HBM.  Work the library puts on streams of its own (ranges of a split
- * batch, small images' kernels, the emulation of dirty restart streams and the second back-end launch behind it) is joined to
- * `hip_stream` before the call returns: whatever the caller enqueues on that stream afterwards sees the final outputs.  Statuses
- * are final after hjd_batch_finish (which may also re-synchronise from the host; hjd_batch_resync_count). */
+ * stream).  Asynchronous; inputs and outputs stay in HBM.  Work the library puts on streams of its own (the decoder's three:
+ * ranges of a split batch, small images' kernels) is joined to `hip_stream` before the call returns.  Outputs and statuses are
+ * final after hjd_batch_finish: that call re-synchronises from the host where the device could not settle a state
+ * (hjd_batch_resync_count) and runs the emulation of restart streams outside the clean-resync domain the FIRST time a batch's
+ * contents need it (the later runs of the same contents carry the emulation launches themselves, on `hip_stream`).
+ * Streams: the HIP runtime has four hardware queues per process (GPU_MAX_HW_QUEUES) and binds a stream to one at the stream's
+ * first command; streams that share a queue run one behind the other.  Create the decoder — and use the streams you will pass
+ * here — early in the process; INTEGRATION.md §9. */
 int hjd_batch_run(hjd_batch *b, void *hip_stream);
 /* Wait for the stream, verify on-device convergence flags, fill status[i] (may be NULL). */
 int hjd_batch_finish(hjd_batch *b, void *hip_stream, int *status);
@@ -205,8 +209,8 @@ int hjd_batch_path_counts(const hjd_batch *b, uint32_t *counts4);
  * (0 in normal operation: the warm-up subsequences of every synchronisation workgroup settled every state). */
 int hjd_batch_resync_count(const hjd_batch *b);
 /* Number of images of this batch that went through the emulation of the reference's sequential decoder (restart streams outside the
- * clean-resync domain) in the runs finished since prepare / reset.  The emulation is enqueued by hjd_batch_run itself, on a
- * side stream: statuses and outputs of such images are final after hjd_batch_finish. */
+ * clean-resync domain) in the runs finished since prepare / reset.  The emulation is enqueued by hjd_batch_finish the first time
+ * these contents need it and by hjd_batch_run afterwards: statuses and outputs of such images are final after hjd_batch_finish. */
 int hjd_batch_sequential_count(const hjd_batch *b);
 /* ... and how many of those were decoded in parallel over the places where the reference resynchronises (csrc/hjd_seq.hip: k_seg_*)
  * rather than by one lane per image. */
