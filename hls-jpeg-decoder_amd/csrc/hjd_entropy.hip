@@ -579,6 +579,238 @@ __device__ __forceinline__ uint4 lds_load<uint4>(uint32_t a)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// The plain form of write_core (no restart markers in sight), instruction by instruction (round 5), for the same reason as
+// sync_window<1>: what this loop costs is its instruction count.  Every region of the C++ loop — DC symbol, AC record, a complete
+// burst, the end of a block — is entered by SOME lane of a wave in nearly every iteration, so a wave executes all of them every
+// time: 78 vector and 35 scalar instructions per iteration as the compiler lays them out (copies of loop-carried values around
+// every region, 64-bit address arithmetic for every store, separate shift / mask / or where one instruction does).  Here an
+// iteration is 58 vector instructions: the next block's tables come from a 16-byte block table read unconditionally beside the
+// look-up (fill_block_table), records leave through an SGPR base + 32-bit offset, the regions are entered by writing EXEC, and the
+// rare cases (a code longer than HJD_LUT_BITS, a block entry or a record that does not fit, the image's last block) sit behind
+// the loop.  v64-v96 are its temporaries.  Same semantics as write_core<false, ...>, statement by statement; `mi` as SyncChain::mi.
+#define KW_WIN "v64"
+#define KW_A "v65"
+#define KW_E "v66"
+#define KW_NW "v67"
+#define KW_MT "v[68:71]"
+#define KW_MT0 "v68"
+#define KW_MT1 "v69"
+#define KW_MT2 "v70"
+#define KW_R03 "v[72:75]"
+#define KW_R47 "v[76:79]"
+#define KW_R01 "v[72:73]"
+#define KW_R23 "v[74:75]"
+#define KW_R45 "v[76:77]"
+#define KW_R67 "v[78:79]"
+#define KW_R0 "v72"
+#define KW_R1 "v73"
+#define KW_LEN "v80"
+#define KW_S "v81"
+#define KW_ADV "v82"
+#define KW_TOT "v83"
+#define KW_T "v84"
+#define KW_OFF "v85"
+#define KW_VAL "v86"
+#define KW_K "v87"
+#define KW_ZW "v88"
+#define KW_SLOT "v89"
+#define KW_W "v90"
+#define KW_RA "v91"
+#define KW_TI "v92"
+#define KW_REL "v93"
+#define KW_EV "v94"
+#define KW_EA "v95"
+#define KW_GO "v96"
+template <uint32_t WGSZ, uint32_t ENTCAP>
+__device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t sec_addr, uint32_t slot_addr, const uint32_t *__restrict__ rowp,
+                                                   uint32_t stride, uint32_t row_bit0, uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end,
+                                                   uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags)
+{
+    static_assert(HJD_REC_RUN == 8 && (WGSZ == 64 || WGSZ == 256), "the burst below: eight records, ring columns WGSZ words apart");
+    static_assert(HJD_FLAG_BAD_CODE == 1u && HJD_FLAG_OVERRUN == 2u, "flag literals below");
+    // bit reader (ReaderLds::init): hi = the word under the cursor, lo = the next one, sh = unconsumed bits of hi
+    const uint32_t rel0 = p - row_bit0, k0 = rel0 >> 5, o0 = rel0 & 31u;
+    const uint32_t *sp = rowp + k0 * stride;
+    uint32_t hi = sp[0], lo = o0 ? sp[stride] : hi, sh = (32u - o0) & 31u;
+    uint32_t nxa = lds_addr(sp + (o0 ? 2u * stride : stride));
+    const uint32_t st4 = stride * 4u;
+    const uint4 cur = lds_load<uint4>(mt4_addr + m * 16u);
+    uint32_t acb = cur.y, tb = z ? cur.y : cur.x, mi = cur.z;
+    uint32_t pend = end, zhi = 0u, bfirst = W.bfirst, bdc = W.bdc, tag = W.tag;
+    const uint32_t ringa = lds_addr(W.ring), enta = lds_addr(W.ent), secm = sec_addr - 2u * HJD_SEC_SIZE;
+    const uint32_t b0 = W.b0, r0 = W.r0, reccap = W.rec_cap, nblocks = W.nblocks;
+    uint32_t *const recp = W.rec;
+    uint2 *const blkp = W.blk;
+    unsigned long long act, isdc, bm, rm, g1, g2, sv0;
+    constexpr int U = WGSZ / 64; // ring columns in units of 64 words (ds_read2st64_b32)
+    asm volatile(
+        "s_mov_b64 %[sv0], exec\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:\n\t"                                                  // ---- look-up (EXEC = the lanes with bits left)
+        "v_alignbit_b32 " KW_WIN ", %[hi], %[lo], %[sh]\n\t"
+        "v_bfe_u32 " KW_A ", " KW_WIN ", %[lb], %[lw]\n\t"
+        "v_lshl_add_u32 " KW_A ", " KW_A ", 1, %[tb]\n\t"
+        "ds_read_u16 " KW_E ", " KW_A "\n\t"
+        "ds_read_b32 " KW_NW ", %[nxa]\n\t"                     // next stream word
+        "ds_read_b128 " KW_MT ", %[mi]\n\t"                     // next block's tables
+        "v_cmp_eq_u32_e64 %[isdc], 0, %[z]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, " KW_LEN "\n\t"
+        "s_and_b64 %[g1], vcc, exec\n\t"
+        "s_cbranch_scc1 4f\n"                                     // a code longer than HJD_LUT_BITS
+        "5:\n\t"
+        // e = length | value bits << 5 | advance << 9; value bits + DetermineSign (loadjpg.cpp:396-409)
+        "v_bfe_u32 " KW_S ", " KW_E ", 5, 4\n\t"
+        "v_lshrrev_b32_e32 " KW_ADV ", 9, " KW_E "\n\t"
+        "v_add_u32_e32 " KW_TOT ", " KW_LEN ", " KW_S "\n\t"
+        "v_lshlrev_b32_e32 " KW_T ", " KW_LEN ", " KW_WIN "\n\t"
+        "v_sub_u32_e32 " KW_OFF ", 32, " KW_TOT "\n\t"
+        "v_bfe_u32 " KW_VAL ", " KW_WIN ", " KW_OFF ", " KW_S "\n\t"
+        "v_lshl_add_u32 " KW_K ", -1, " KW_S ", 1\n\t"          // 1 - 2^s
+        "v_cmp_gt_i32_e32 vcc, 0, " KW_T "\n\t"                 // leading value bit set: the value as it is
+        "v_cndmask_b32_e64 " KW_K ", " KW_K ", 0, vcc\n\t"
+        "v_add_u32_e32 " KW_VAL ", " KW_VAL ", " KW_K "\n\t"
+        "v_add3_u32 " KW_ZW ", %[z], " KW_ADV ", -1\n\t"
+        "v_add_u32_e32 %[z], %[z], " KW_ADV "\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, " KW_S "\n\t"
+        "v_cndmask_b32_e64 %[bfirst], %[bfirst], %[nrec], %[isdc]\n\t"  // DC symbol (loadjpg.cpp:562-667): the block's entry begins here
+        "v_cndmask_b32_e64 %[bdc], %[bdc], " KW_VAL ", %[isdc]\n\t"
+        "v_cndmask_b32_e64 %[tb], %[tb], %[acb], %[isdc]\n\t"
+        "v_cmp_lt_u32_e64 %[bm], 63, %[z]\n\t"                    // EOB or last coefficient
+        "s_andn2_b64 %[rm], vcc, %[isdc]\n\t"                     // AC run/size with a value (loadjpg.cpp:776-808): a record
+        "s_mov_b64 %[act], exec\n\t"
+        "s_mov_b64 exec, %[rm]\n\t"                               // ---- record
+        "v_and_or_b32 " KW_A ", " KW_ZW ", 63, %[slotb]\n\t"
+        "ds_read_u8 " KW_SLOT ", " KW_A "\n\t"
+        "v_or_b32_e32 %[zhi], %[zhi], " KW_ZW "\n\t"            // zw > 63 (bit 6): flagged after the loop
+        "v_and_b32_e32 " KW_RA ", 7, %[nrec]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 7, " KW_RA "\n\t"
+        "v_lshl_add_u32 " KW_RA ", " KW_RA ", %[lgcol], %[ringa]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshl_or_b32 " KW_W ", " KW_SLOT ", 16, %[tag]\n\t"
+        "v_bfi_b32 " KW_W ", %[m16], " KW_VAL ", " KW_W "\n\t"
+        "ds_write_b32 " KW_RA ", " KW_W "\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                           // lanes whose burst is complete: whole, aligned sectors
+        "s_cbranch_execz 7f\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[reccap], %[nrec]\n\t"
+        "s_andn2_b64 %[g1], exec, vcc\n\t"
+        "s_cbranch_scc1 8f\n"                                     // a burst past the image's record space
+        "6:\n\t"
+        "ds_read2st64_b32 " KW_R01 ", %[ringa] offset0:%[c0] offset1:%[c1]\n\t"
+        "ds_read2st64_b32 " KW_R23 ", %[ringa] offset0:%[c2] offset1:%[c3]\n\t"
+        "ds_read2st64_b32 " KW_R45 ", %[ringa] offset0:%[c4] offset1:%[c5]\n\t"
+        "ds_read2st64_b32 " KW_R67 ", %[ringa] offset0:%[c6] offset1:%[c7]\n\t"
+        "v_lshlrev_b32_e32 " KW_GO ", 2, %[nrec]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "global_store_dwordx4 " KW_GO ", " KW_R03 ", %[recp] offset:-28\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "global_store_dwordx4 " KW_GO ", " KW_R47 ", %[recp] offset:-12\n"
+        "7:\n\t"
+        "s_mov_b64 exec, %[rm]\n\t"
+        "v_add_u32_e32 %[nrec], 1, %[nrec]\n\t"
+        "s_mov_b64 exec, %[bm]\n\t"                               // ---- end of block: next block (DecodeMCU order, loadjpg.cpp:945-997)
+        "v_cmp_ne_u32_e32 vcc, -1, %[bfirst]\n\t"                 // (all ones: the block began in an earlier span, no entry from here)
+        "v_sub_u32_e32 " KW_TI ", %[nblk], %[b0]\n\t"
+        "v_sub_u32_e32 " KW_REL ", %[bfirst], %[r0]\n\t"
+        "v_cmp_gt_u32_e64 %[g1], %[entcap], " KW_TI "\n\t"
+        "v_cmp_gt_u32_e64 %[g2], %[m16], " KW_REL "\n\t"
+        "s_and_b64 %[g1], %[g1], %[g2]\n\t"
+        "s_andn2_b64 %[g2], vcc, %[g1]\n\t"
+        "s_cbranch_scc1 9f\n"                                     // more blocks or records than the staging holds: straight out
+        "10:\n\t"
+        "v_lshl_or_b32 " KW_EV ", %[bdc], 16, " KW_REL "\n\t"
+        "v_lshl_add_u32 " KW_EA ", " KW_TI ", 2, %[enta]\n\t"
+        "s_and_b64 exec, vcc, %[g1]\n\t"
+        "ds_write_b32 " KW_EA ", " KW_EV "\n\t"
+        "s_mov_b64 exec, %[bm]\n\t"
+        "v_mov_b32_e32 %[bfirst], -1\n\t"
+        "v_add_u32_e32 %[nblk], 1, %[nblk]\n\t"
+        "v_lshlrev_b32_e32 %[tag], 22, %[nblk]\n\t"
+        "v_and_b32_e32 %[tag], %[tagm], %[tag]\n\t"
+        "v_cmp_eq_u32_e32 vcc, %[nblocks], %[nblk]\n\t"
+        "s_and_b64 %[g1], vcc, exec\n\t"
+        "s_cbranch_scc1 11f\n"                                    // the image is complete
+        "12:\n\t"
+        "v_mov_b32_e32 %[z], 0\n\t"
+        "v_mov_b32_e32 %[tb], " KW_MT0 "\n\t"
+        "v_mov_b32_e32 %[acb], " KW_MT1 "\n\t"
+        "v_mov_b32_e32 %[mi], " KW_MT2 "\n\t"
+        "s_mov_b64 exec, %[act]\n\t"                              // ---- the bit reader moves on
+        "v_sub_u32_e32 %[sh], %[sh], " KW_TOT "\n\t"
+        "v_add_u32_e32 %[p], %[p], " KW_TOT "\n\t"
+        "v_cmp_gt_i32_e32 vcc, 0, %[sh]\n\t"
+        "v_cndmask_b32_e32 %[hi], %[hi], %[lo], vcc\n\t"
+        "v_cndmask_b32_e32 %[lo], %[lo], " KW_NW ", vcc\n\t"
+        "v_cndmask_b32_e32 " KW_T ", 0, %[st4], vcc\n\t"
+        "v_add_u32_e32 %[nxa], %[nxa], " KW_T "\n\t"
+        "v_and_b32_e32 %[sh], 31, %[sh]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[p], %[pend]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_branch 3f\n"
+        "4:\n\t"                                                  // ---- second-level table on the next HJD_SEC_BITS bits (IsInHuffmanCodes,
+        "s_mov_b64 %[act], exec\n\t"                              //      loadjpg.cpp:335-392, for the lengths the primary table cannot hold)
+        "s_mov_b64 exec, %[g1]\n\t"
+        "v_lshrrev_b32_e32 " KW_T ", 5, " KW_E "\n\t"           // 1 + table index, 0 = no code has this prefix
+        "v_bfe_u32 " KW_A ", " KW_WIN ", 16, %[sw]\n\t"
+        "v_lshl_add_u32 " KW_A ", " KW_T ", %[sw], " KW_A "\n\t"
+        "v_lshl_add_u32 " KW_A ", " KW_A ", 1, %[secm]\n\t"
+        "ds_read_u16 " KW_A ", " KW_A "\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, " KW_T "\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cndmask_b32_e32 " KW_E ", 0, " KW_A ", vcc\n\t"
+        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, " KW_LEN "\n\t"
+        "v_cndmask_b32_e64 " KW_T ", 0, 1, vcc\n\t"
+        "v_or_b32_e32 %[flags], %[flags], " KW_T "\n\t"         // HJD_FLAG_BAD_CODE
+        "v_cndmask_b32_e64 " KW_E ", " KW_E ", 16, vcc\n\t"     // skip 16 bits: any progress will do, the result is flagged
+        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "s_branch 5b\n"
+        "8:\n\t"                                                  // ---- bursts past the record space are not stored (g1: those lanes)
+        "s_mov_b64 %[g2], exec\n\t"
+        "s_mov_b64 exec, %[g1]\n\t"
+        "v_or_b32_e32 %[flags], 2, %[flags]\n\t"                  // HJD_FLAG_OVERRUN
+        "s_andn2_b64 exec, %[g2], %[g1]\n\t"
+        "s_branch 6b\n"
+        "9:\n\t"                                                  // ---- block entries that do not fit the staging (g2: those lanes)
+        "s_mov_b64 exec, %[g2]\n\t"
+        "v_mov_b32_e32 " KW_R0 ", %[bfirst]\n\t"
+        "v_and_b32_e32 " KW_R1 ", %[m16], %[bdc]\n\t"
+        "v_lshlrev_b32_e32 " KW_GO ", 3, %[nblk]\n\t"
+        "s_nop 0\n\t"
+        "global_store_dwordx2 " KW_GO ", " KW_R01 ", %[blkp]\n\t"
+        "s_mov_b64 exec, %[bm]\n\t"
+        "s_branch 10b\n"
+        "11:\n\t"                                                 // ---- the last block (g1: those lanes): end of its records; what follows is not looked at
+        "s_mov_b64 exec, %[g1]\n\t"
+        "v_mov_b32_e32 " KW_R0 ", %[nrec]\n\t"
+        "v_mov_b32_e32 " KW_R1 ", 0\n\t"
+        "v_lshlrev_b32_e32 " KW_GO ", 3, %[nblk]\n\t"
+        "v_add_u32_e32 %[pend], %[p], " KW_TOT "\n\t"
+        "global_store_dwordx2 " KW_GO ", " KW_R01 ", %[blkp]\n\t"
+        "s_mov_b64 exec, %[bm]\n\t"
+        "s_branch 12b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sv0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [p] "+v"(p), [z] "+v"(z), [sh] "+v"(sh), [hi] "+v"(hi), [lo] "+v"(lo), [nxa] "+v"(nxa), [tb] "+v"(tb), [acb] "+v"(acb), [mi] "+v"(mi),
+          [nblk] "+v"(nblk), [nrec] "+v"(nrec), [bfirst] "+v"(bfirst), [bdc] "+v"(bdc), [tag] "+v"(tag), [flags] "+v"(flags), [zhi] "+v"(zhi),
+          [pend] "+v"(pend), [act] "=&s"(act), [isdc] "=&s"(isdc), [bm] "=&s"(bm), [rm] "=&s"(rm), [g1] "=&s"(g1), [g2] "=&s"(g2), [sv0] "=&s"(sv0)
+        : [ringa] "v"(ringa), [enta] "v"(enta), [secm] "v"(secm), [slotb] "v"(slot_addr), [st4] "v"(st4), [b0] "v"(b0), [r0] "v"(r0),
+          [reccap] "s"(reccap), [nblocks] "s"(nblocks), [entcap] "s"(ENTCAP), [m16] "s"(0xFFFFu), [tagm] "s"(0x1FC00000u), [recp] "s"(recp),
+          [blkp] "s"(blkp), [lb] "n"(32 - HJD_LUT_BITS), [lw] "n"(HJD_LUT_BITS), [sw] "n"(HJD_SEC_BITS), [lgcol] "n"(WGSZ == 256 ? 10 : 8),
+          [c0] "n"(0 * U), [c1] "n"(1 * U), [c2] "n"(2 * U), [c3] "n"(3 * U), [c4] "n"(4 * U), [c5] "n"(5 * U), [c6] "n"(6 * U), [c7] "n"(7 * U)
+        : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96");
+    flags |= (zhi >> 5) & HJD_FLAG_OVERRUN; // zw <= 63 + 15, so bit 6 says it
+    m = lds_load<uint32_t>(mi + 12u);       // the block in progress
+    W.bfirst = bfirst;
+    W.bdc = bdc;
+    W.tag = tag;
+}
+
 // All chains of a lane through one staging window: until every chain's bit position has reached pend[c] (relative to the
 // window's first bit; 0 = the chain takes no part).  sec_addr: LDS byte address of the second-level tables.
 template <int NC>
@@ -2126,7 +2358,8 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
     uint32_t *s_w = s_dyn + P.lds_state_word;
     uint8_t *s_slot = reinterpret_cast<uint8_t *>(s_w + 32);
     uint2 *s_mt = reinterpret_cast<uint2 *>(s_w + 48);
-    uint32_t *s_ring = s_w + 64;                        // [HJD_REC_RUN][WGSZ]: the lanes' bursts in the making
+    uint4 *s_mt4 = reinterpret_cast<uint4 *>(s_w + 64); // block table of the hand-written loop (fill_block_table): six entries
+    uint32_t *s_ring = s_w + 96;                        // [HJD_REC_RUN][WGSZ]: the lanes' bursts in the making
     uint32_t *s_ent = s_ring + HJD_REC_RUN * WGSZ; // [ENTCAP]: block entries in the making
     uint32_t *s_rows = s_ent + ENTCAP;
     const HjdTableSet *ts = &P.tabs[im.tabset];
@@ -2142,6 +2375,8 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
     if (tid < 64) s_slot[tid] = c_zz_to_slot[tid];
     for (uint32_t k = tid; k < ENTCAP; k += WGSZ) s_ent[k] = 0xFFFFFFFFu;
     fill_mcu_table(s_mt, im.nb, im.nby, table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u), table_pair(ts->slot_pack, 2, 2u));
+    fill_block_table(s_mt4, lds_addr(s_mt4), im.nb, im.nby, lds_addr(s_lut), table_pair(ts->slot_pack, 0, 2u), table_pair(ts->slot_pack, 1, 2u),
+                     table_pair(ts->slot_pack, 2, 2u), tid);
     {   // the workgroup's rows: word k of row i0 + r -> s_rows[k * stride + r] (rows past the scan's end stay unread)
         const uint32_t i0 = wg * G, nrows = min(G, nsub - i0), lw = P.log2_words;
         const uint32_t *wbase = reinterpret_cast<const uint32_t *>(P.ustream + im.ustream_off);
@@ -2234,7 +2469,7 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
             rc.mk = min(P.submk[g], rc.nmark); // first marker past the subsequence's first bit (k_sync); write_span moves it past p
             write_span<true, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
         } else {
-            write_span<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, im.nby, im.nb, p, z, m, pend, blk, nrec, W, flags, rc);
+            write_window_plain<WGSZ, ENTCAP>(lds_addr(s_mt4), lds_addr(s_sec), lds_addr(s_slot), rowp, stride, row_bit0, p, z, m, pend, blk, nrec, W, flags);
         }
     }
     // the span must end in the state, and with the record count, its checkpoints hold (else the places of everything

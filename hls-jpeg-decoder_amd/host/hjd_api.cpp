@@ -760,7 +760,7 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.phase_words = wpp;
         P.write_windows = wwn;
         P.lds_sec_word = max_nlut * HJD_LUT_SIZE / 2;
-        P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 3) & ~3u;
+        P.lds_state_word = (P.lds_sec_word + max_nsec * (HJD_SEC_SIZE / 2) + 15) & ~15u; // 64-byte aligned: k_write's slot table is addressed by OR
         P.lds_sec_word_s = max_nlut * HJD_LUT_SIZE_S; // two u16 entries per index
         P.lds_state_word_s = (P.lds_sec_word_s + max_nsec_s * (HJD_SEC_SIZE_S / 2) + 3) & ~3u;
         // k_sync: five word arrays + the u8 marks + 96 words (scratch, block tables), then one staging window per slot (the first
@@ -769,8 +769,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         P.lds_bytes_sync_seq = (P.lds_state_word_s + 48 + (wpp + 2) * 64) * 4;
         P.lds_bytes_sync_small = (P.lds_state_word_s + 5 * HJD_SYNC_WG_SMALL + HJD_SYNC_WG_SMALL / 4 + 96 + (HJD_SYNC_WG_SMALL / 64) * (wpp + 2) * 64) * 4;
         // k_write: scan scratch, slot table, block table, the lanes' record bursts, then the workgroup's rows ([word][row], rows + 1 apart)
-        P.lds_bytes_write = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG + HJD_ENT_CAP + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
-        P.lds_bytes_write_small = (P.lds_state_word + 64 + HJD_REC_RUN * HJD_WRITE_WG_SMALL + HJD_ENT_CAP_SMALL +
+        P.lds_bytes_write = (P.lds_state_word + 96 + HJD_REC_RUN * HJD_WRITE_WG + HJD_ENT_CAP + (S / 32 + 2) * (HJD_WRITE_WG / nu + 1)) * 4;
+        P.lds_bytes_write_small = (P.lds_state_word + 96 + HJD_REC_RUN * HJD_WRITE_WG_SMALL + HJD_ENT_CAP_SMALL +
                                    (S / 32 + 2) * (HJD_WRITE_WG_SMALL / (nu <= HJD_WRITE_WG_SMALL ? nu : HJD_WRITE_WG_SMALL) + 1)) * 4;
     }
     if (b->dry || !b->nimg) return HJD_OK;
