@@ -46,6 +46,8 @@ struct EntropyLds {
     const uint16_t *sec; // [nsec][HJD_SEC_SIZE]
     const uint2 *mt;     // [nb] block-in-MCU m -> (byte offsets DC | AC << 16 of its tables, next m): the block-end step is
                          // taken by some lane of a wave in nearly every iteration, so it is two LDS reads instead of nine VALU
+    uint32_t mt4_addr, sec_addr, slot_addr; // k_write only: LDS byte addresses of the hand-written loop's block table
+                                            // (fill_block_table), of the second-level tables and of the slot table
 };
 
 // fills EntropyLds::mt (first nb lanes; the caller synchronises)
@@ -180,6 +182,12 @@ struct WriteCtx {
     uint32_t *ent;          // LDS: the workgroup's block entries in the making (HJD_ENT_CAP words, all ones = not written here)
     uint32_t b0, r0;        // the workgroup's first block / first record
 };
+
+// (defined below, behind the LDS helpers it uses)
+template <uint32_t WGSZ, uint32_t ENTCAP>
+__device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t sec_addr, uint32_t slot_addr, const uint32_t *__restrict__ rowp,
+                                                   uint32_t stride, uint32_t row_bit0, uint32_t &p, uint32_t &z, uint32_t &m, uint32_t end,
+                                                   uint32_t &nblk, uint32_t &nrec, WriteCtx &W, uint32_t &flags);
 
 // The entry of block b = (first record, DC difference), made by the lane that decoded the block's DC symbol (bfirst != ~0), when
 // the block ends or the lane's span does.  A workgroup's blocks are consecutive, so the entries wait in LDS — 4 bytes: first
@@ -494,7 +502,7 @@ __device__ __forceinline__ void write_span(const EntropyLds &L, const uint32_t *
         // inside the span — no marker where the block count says one should be — is the DIRTY verdict the loop with the rules gives
         // (loadjpg.cpp:535-550 never fires there, the reference decodes on)
         const uint32_t before = nblk;
-        write_core<false, WGSZ, ENTCAP>(L, rowp, stride, row_bit0, tabY, tabCb, tabCr, nby, nb, p, z, m, end, nblk, nrec, W, flags, rc);
+        if (p < end) write_window_plain<WGSZ, ENTCAP>(L.mt4_addr, L.sec_addr, L.slot_addr, rowp, stride, row_bit0, p, z, m, end, nblk, nrec, W, flags);
         const uint32_t done = nblk - before;
         if (!rc.conf && rc.ri_blocks != 0u) {
             if (done >= rc.left && before + rc.left < W.nblocks) {
@@ -2460,7 +2468,7 @@ __device__ __forceinline__ void write_body(const HjdParams &P)
     const uint32_t row_bit0 = i * S;
     const uint32_t pend = min(row_bit0 + (ph + WWN) * P.phase_words * 32u, min(row_bit0 + S, total_bits));
     if (go && p < pend && blk < im.nblocks) {
-        const EntropyLds L = {s_lut, s_sec, s_mt};
+        const EntropyLds L = {s_lut, s_sec, s_mt, lds_addr(s_mt4), lds_addr(s_sec), lds_addr(s_slot)};
         const uint32_t tabY = table_pair(ts->slot_pack, 0, 2u), tabCb = table_pair(ts->slot_pack, 1, 2u), tabCr = table_pair(ts->slot_pack, 2, 2u);
         const uint32_t *rowp = s_rows + (i - wg * G);
         RestartCtx rc = {P.mpos + im.mark_off, 0u, 0u, im.ri_blocks, im.ri_blocks ? im.ri_blocks - blk % im.ri_blocks : 0u, im.conformant};
