@@ -19,7 +19,7 @@ fi
 if [ "$PART" = b ]; then
   python3 bench.py --width 1920 --height 1080 --batch 1024 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_config3_bench.json
   rm -f $O/${TAG}_config5_bench.json
-  for m in "--caller-streams 2" "--caller-streams 2 --hostile" "--caller-streams 1 --internal-streams 0" "--caller-streams 1 --internal-streams 0 --hostile" "--caller-streams 4" "--caller-streams 1 --internal-streams 4"; do
+  for m in "--caller-streams 4" "--caller-streams 4 --hostile" "--caller-streams 1 --internal-streams 0" "--caller-streams 1 --internal-streams 0 --hostile" "--caller-streams 2" "--caller-streams 1 --internal-streams 4" "--caller-streams 4 --images 512"; do
     python3 tools/config5_bench.py $m 2>/dev/null | python3 -c "$J" >> $O/${TAG}_config5_bench.json
   done
   python3 bench.py --content photo --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_photo_bench.json
