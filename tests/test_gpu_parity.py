@@ -776,6 +776,57 @@ def test_reference_shaped_entry_points(hjd, golden):
     assert L.hjd_last_status() == hjd.HJD_ERR_NOT_JPEG
 
 
+@pytest.mark.gpu
+def test_four_caller_streams_mixed_batches(hjd):
+    """Four batches of one decoder on four caller streams, enqueued step after step without a host synchronisation in between
+    (BASELINE config 5's shape in the small): large and small images, restart streams inside and outside the clean-resync domain.
+    With three or more caller streams in flight the library keeps the small images' kernels on the run's own stream; the
+    emulation of the dirty restart streams is enqueued by the FIRST finish of a batch's contents and by the runs after it
+    (hjd_api.cpp: emulation_enqueue) — the outputs of a batch that is run once, of one that is run again after its finish, and of
+    one finished after several runs must all equal the oracle's, and the emulation counters must say which images took it."""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(3)]
+    d = hjd.Decoder(0)
+    specs = [(1000, 700, 2, 2, 0, 7.0, 4100), (250, 187, 2, 1, 0, 7.0, 4101), (640, 480, 1, 1, 40, 7.0, 4102), (64, 48, 2, 2, 0, 7.0, 4103),
+             (512, 384, 2, 1, 7, 0.5, 4289), (640, 480, 2, 2, 1, 6.0, 4100), (1280, 720, 2, 2, 80, 7.0, 4106), (96, 80, 4, 1, 0, 7.0, 4107),
+             (320, 240, 1, 1, 2, 0.5, 4105)]   # three of them dirty (test_segment_parallel_emulation_equals_the_one_lane_kernel's)
+    jpgs = [T.synth_jpeg(w, h, seed, 85, hf, vf, rst, sg) for (w, h, hf, vf, rst, sg, seed) in specs]
+    want = [T.oracle_decode(j) for j in jpgs]
+    batches = [d.prepare([jpgs[(k + q) % len(jpgs)] for q in range(6)]) for k in range(4)]
+    order = [[(k + q) % len(jpgs) for q in range(6)] for k in range(4)]
+
+    def check(b, idx, st):
+        for i, g in enumerate(idx):
+            orc, orgb = want[g][0], want[g][1]
+            if orc == 0:
+                assert st[i] == 0, (specs[g], st[i])
+                assert np.array_equal(b.download(i), orgb), specs[g]
+            else:
+                assert st[i] != 0, specs[g]
+
+    # run once, finish: the first finish enqueues the emulation for the contents that need it
+    for b, ts in zip(batches, streams):
+        b.run(ts.cuda_stream)
+    for b, ts, idx in zip(batches, streams, order):
+        check(b, idx, b.finish(ts.cuda_stream))
+    dirty = sum(b.sequential_count() for b in batches)
+    # three steps back to back on the four streams, then the finishes: these runs carry the emulation themselves
+    for _ in range(3):
+        for b, ts in zip(batches, streams):
+            b.run(ts.cuda_stream)
+    for b, ts, idx in zip(batches, streams, order):
+        check(b, idx, b.finish(ts.cuda_stream))
+    # the images on which the oracle took the dirty branches and decoded: emulated here, once per batch that holds them and finish
+    n_dirty = sum(1 for idx in order for g in idx if want[g][0] == 0 and want[g][4].resyncs_dirty)
+    assert n_dirty >= 4 and dirty == n_dirty, (dirty, n_dirty)
+    assert sum(b.sequential_count() for b in batches) == 2 * n_dirty   # ... and once more for the second finish
+    assert all(b.resync_count() == 0 for b in batches)
+    for b in batches:
+        b.close()
+    d.close()
+
+
 @pytest.mark.parametrize("streams", [2, 3, 7])
 def test_internal_streams(hjd, golden, streams):
     """hjd_options.streams: the batch is split into contiguous image ranges on internal HIP streams,
