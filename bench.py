@@ -208,6 +208,7 @@ def main():
                          "with per-image optimised Huffman tables — not the driver's workload, a second data point")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images per GPU, replicated to fill its share (16: profiles/r04_bench_distinct16.json)")
     ap.add_argument("--subseq-bits", type=int, default=0)
+    ap.add_argument("--launches-per-stream", type=int, default=1, help="batches per caller stream and step (the rank's share is dealt to streams x this many batches)")
     ap.add_argument("--streams", type=int, default=4, help="split the per-GPU share over this many HIP streams")
     ap.add_argument("--internal-streams", type=int, default=0,
                     help="instead: ONE batch, split inside the library (hjd_options.streams); no per-stage timing")
@@ -267,21 +268,21 @@ def main():
     mine = parts_global[rank]
     assert sorted(sum(parts_global, [])) == list(range(n_global))
     src_ids = sorted({g % n_src for g in mine})
-    if args.internal_streams > 1:
+    if args.internal_streams > 1 or args.internal_streams < 0:  # the split is the library's (-1: its own choice by batch size): one caller stream
         args.streams = 1
     # The caller streams FIRST, before the library creates any of its own: the HIP runtime gives the first four streams of a process
     # (the default stream and the next three) a hardware queue each and lets every later one share the least used — two caller
     # streams that share a queue run one behind the other (round 5, rocprofv3 Queue_Id: four fresh streams created after the
     # decoder sat on three queues, 288 Gpixel/s against 323; BASELINE config 5: 131 against 169).  INTEGRATION.md §streams.
-    ns = max(1, min(args.streams, len(mine)))
+    nstreams = max(1, min(args.streams, len(mine)))
     torch.zeros(1, device="cuda:%d" % local_rank)  # the default stream's hardware queue exists before any other stream is created
     torch.cuda.synchronize()
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     for ts in tstreams:  # ... and USED once: the runtime binds a stream to its hardware queue at the stream's first command
         with torch.cuda.stream(ts):
             torch.zeros(1, device="cuda:%d" % local_rank)
     torch.cuda.synchronize()
-    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=max(1, args.internal_streams))  # 1 = no split inside the library
+    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=0 if args.internal_streams < 0 else max(1, args.internal_streams))  # 1 = no split inside the library, 0 = the library's choice
     if args.content == "photo":
         import numpy as np
         pb = dec.prepare([open(os.path.join(ROOT, "tests", "golden", "Lenna.jpg"), "rb").read()], hjd.OUT_RGB)
@@ -304,7 +305,8 @@ def main():
     # parse + H2D: inputs are resident in HBM from here on.  The per-GPU share may be split into
     # sub-batches that run on separate HIP streams, so that one sub-batch's latency-bound
     # synchronisation tail overlaps another's IDCT (same total work per step).
-    ns = max(1, min(args.streams, len(jpgs)))
+    # ns = batches = launches of every kernel per step; --launches-per-stream L > 1: L batches one behind the other on every stream
+    ns = max(1, min(nstreams * max(1, args.launches_per_stream), len(jpgs)))
     parts = [jpgs[k::ns] for k in range(ns)]
     part_src = [[mine[i] % n_src for i in range(k, len(jpgs), ns)] for k in range(ns)]
     batches = [dec.prepare(p, hjd.OUT_RGB) for p in parts]
@@ -312,7 +314,7 @@ def main():
         assert all(s == 0 for s in b.parse_status), b.parse_status
     tot = [b.totals() for b in batches]
     pixels, alg_bytes, scan_bytes = (sum(t[k] for t in tot) for k in range(3))
-    streams = [ts.cuda_stream for ts in tstreams]
+    streams = [tstreams[j % nstreams].cuda_stream for j in range(ns)]
 
     def barrier():
         if world > 1:  # a failed barrier ends this rank (non-zero) at once; the launcher ends the others
@@ -330,7 +332,7 @@ def main():
     # the first of them — so that between the last warm-up step and the first timed one lies a barrier and nothing else: with the
     # statuses fetched and 340 events created in between, the timed region began on a GPU that had been idle for a millisecond
     # or two (the first region of a run was 5 % below the following ones, with or without stage events).
-    timed_batches = [] if (args.internal_streams > 1 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
+    timed_batches = [] if (args.internal_streams > 1 or args.internal_streams < 0 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
     for b in timed_batches:
         b.enable_timing(args.steps + args.warmup)
     for _ in range(args.warmup):
@@ -494,7 +496,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "stage": dom[0],
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": per_kernel.get(dom[0], {}).get("traffic"),
-                "timing": timing + (": hipEvents around the stage inside the timed region (the launches of %s), other streams' kernels beside it" % ("one of the %d streams: one launch per step" % ns if len(timed_batches) == 1 and ns > 1 else "every stream")
+                "timing": timing + (": hipEvents around the stage inside the timed region (the launches of %s), other streams' kernels beside it" % ("one of the %d batches of a step, %d caller streams" % (ns, nstreams) if len(timed_batches) == 1 and ns > 1 else "every batch")
                                     if timing == "overlapped" else ": no stage events in the timed region"),
                 "kernel_ms": round(dom[1], 4),
                 "kernel_ms_isolated": round(iso.get(dom[0], 0.0), 4),

@@ -200,7 +200,6 @@ struct hjd_batch {
     // and a join event on the caller's stream (one range's latency-bound synchronisation overlaps another's IDCT)
     struct Range { int i0, i1; uint32_t rst0, nrst; uint32_t chunk0, nchunk, syncwg0, nsyncwg, ssyncwg0, nssyncwg, repwg0, nrepwg, writewg0, nwritewg, swritewg0, nswritewg, seq0, nseq, side_feeds_big, dc0, ndc, group0, ngroup; size_t blk0, nblk; };
     std::vector<Range> ranges;
-    std::vector<hipStream_t> istreams;
     std::vector<hipEvent_t> join_ev;
     std::vector<hipEvent_t> stagger_ev; // per range: recorded after its synchronisation (or final pass), the next range waits for it
     hipEvent_t fork_ev = nullptr;
@@ -485,8 +484,6 @@ static void batch_free_device(hjd_batch *b)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     for (auto &v : b->tev)
         for (auto &e : v) (void)hipEventDestroy(e);
-    for (size_t k = 4; k < b->istreams.size(); k++) // (1..3 belong to the decoder)
-        if (b->istreams[k]) (void)hipStreamDestroy(b->istreams[k]);
     for (auto &e : b->join_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : b->stagger_ev)
@@ -993,8 +990,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         uint64_t total_px = 0;
         for (auto &im : b->img) total_px += (uint64_t)im.width * im.height;
         int ns = d->streams;
-        if (ns == 0) // measured on 4K images, one caller stream: 8..32 images +4 % with two ranges, 64 images +17 % with three
-            ns = total_px >= 400000000ull ? 3 : (total_px >= 60000000ull ? 2 : 1);
+        if (ns == 0) { // measured on 4K images, one caller stream: 8..32 images +4 % with two ranges, 64 images +17 % with three;
+                       // large batches: ranges of about 130 Mpixel (the size of launch that overlaps best), at most 16 — dealt to
+                       // four streams by batch_enqueue
+            ns = total_px >= 400000000ull ? (int)((total_px + 66000000ull) / 133000000ull) : (total_px >= 60000000ull ? 2 : 1);
+            if (ns > 16) ns = 16;
+        }
         if (ns > b->nimg) ns = b->nimg;
         if (ns < 1) ns = 1;
         int i0 = 0;
@@ -1092,25 +1093,18 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         // the decoder's three streams: ranges 1..3 first, what is left to the side streams of ranges 0, 1, ... (none: that range's
         // small kernels follow its large one on the range's own stream) — a batch and the caller's stream stay within four queues
         for (size_t k = 0; k < b->small_side.size(); k++) {
-            const size_t nr = b->ranges.size() > 1 ? b->ranges.size() : 1, idx = nr - 1 + k;
+            const size_t nr = b->ranges.size() > 4 ? 4 : (b->ranges.size() > 1 ? b->ranges.size() : 1), idx = nr - 1 + k; // queues the ranges take
             b->small_side[k].st = idx < 3 ? b->dec->lib_streams[idx] : nullptr;
         }
         if (!b->rst_images.empty() && !b->seq_done) {
             HIPCHK(hipEventCreateWithFlags(&b->seq_done, hipEventDisableTiming));
         }
         if (b->ranges.size() > 1) {
-            while (b->istreams.size() < b->ranges.size()) {
-                hipStream_t st = nullptr; // entry 0 stays empty: range 0 runs on the caller's stream
-                hipEvent_t e = nullptr;
-                if (!b->istreams.empty()) {
-                    if (b->istreams.size() <= 3) st = b->dec->lib_streams[b->istreams.size() - 1];
-                    else HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); // more than four ranges: streams of the batch's own
-                    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                }
-                b->istreams.push_back(st);
-                b->join_ev.push_back(e);
-                hipEvent_t se = nullptr;
+            while (b->join_ev.size() < b->ranges.size()) { // (the ranges' streams are the decoder's: batch_enqueue)
+                hipEvent_t e = nullptr, se = nullptr;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&se, hipEventDisableTiming));
+                b->join_ev.push_back(e);
                 b->stagger_ev.push_back(se);
             }
             if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
@@ -1501,22 +1495,28 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         int rc = range_enqueue(b, all, s, from_resync, nstage, names, evs);
         return rc ? rc : emulation_enqueue(b, s);
     }
-    // range 0 stays on the caller's stream, the others fork off it: n ranges occupy n hardware queues, not n + 1 (a
-    // process has four by default; a fifth stream shares one and serialises behind it).  Ranges are enqueued in order,
-    // range k's synchronisation waiting for range k-1's (stagger = 1) or for range k-1's final pass (stagger = 2): the
-    // ranges then run as a software pipeline — one in its latency-bound synchronisation, the others in their
-    // issue-bound final pass / IDCT — instead of all in the same stage at the same time.
+    // The ranges are dealt round robin to at most four streams — the caller's and the decoder's three (a process has four hardware
+    // queues) — and run one behind the other on each: a batch of 2 Gpixel is sixteen ranges of the size that
+    // overlaps best (about 130 Mpixel: the headline's launches), four at a time, like a caller that deals sixteen batches to four
+    // streams (BASELINE config 3 as sixteen batches on four caller streams 314 Gpixel/s, as four 286).  With three or more caller
+    // streams in flight (callers_seen) everything stays on the caller's stream: the other runs are what this one overlaps with.
+    // Ranges are enqueued in order; with HJD_STAGGER range k's synchronisation waits for range k-1's (or for its final pass).
     const int stagger = from_resync ? 0 : b->dec->stagger;
-    HIPCHK(hipEventRecord(b->fork_ev, s));
-    for (size_t k = 0; k < b->ranges.size(); k++) {
-        hipStream_t sk = k ? b->istreams[k] : s;
-        if (k) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0));
+    const size_t nr = b->ranges.size();
+    const size_t nq = b->callers_seen >= 3 ? 1 : (nr < 4 ? nr : 4);
+    if (nq > 1) HIPCHK(hipEventRecord(b->fork_ev, s));
+    for (size_t k = 0; k < nr; k++) {
+        const size_t q = k % nq;
+        hipStream_t sk = q ? b->dec->lib_streams[q - 1] : s;
+        if (q && k < nq) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0)); // a stream's first range of this run
         int rc = range_enqueue(b, b->ranges[k], sk, from_resync, nullptr, nullptr, nullptr,
-                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, k);
+                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, nq > 1 ? k : nr);
         if (rc) return rc;
-        if (k) HIPCHK(hipEventRecord(b->join_ev[k], sk));
     }
-    for (size_t k = 1; k < b->ranges.size(); k++) HIPCHK(hipStreamWaitEvent(s, b->join_ev[k], 0));
+    for (size_t q = 1; q < nq; q++) {
+        HIPCHK(hipEventRecord(b->join_ev[q], b->dec->lib_streams[q - 1]));
+        HIPCHK(hipStreamWaitEvent(s, b->join_ev[q], 0));
+    }
     return emulation_enqueue(b, s);
 }
 

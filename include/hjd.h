@@ -117,9 +117,11 @@ typedef struct hjd_options {
     int subseq_bits;     /* entropy-decode subsequence size in bits (power of two, 64..16384); 0 = chosen per batch from its scan bytes */
     int sync_launches;   /* 1 + in-stream repair launches after the synchronisation launch; 0 = default (1: the final pass checks
                           * every start state and hjd_batch_finish repairs from the host if one is ever stale) */
-    int streams;         /* image ranges a batch is split into, each on its own HIP stream (the first on the caller's; the
-                          * others forked from and joined to it): one range's latency-bound synchronisation then overlaps
-                          * another's IDCT.  0 = by batch size (1 below 60 Mpixel, 2 up to 400, 3 above), 1 = no split */
+    int streams;         /* image ranges a batch is split into.  The ranges are dealt round robin to at most four HIP streams (the caller's
+                          * and three of the decoder's, forked from and joined to the caller's inside every run) and run one behind the
+                          * other on each: one range's latency-bound synchronisation overlaps another's IDCT.  With three or more caller
+                          * streams in flight on the decoder all ranges stay on the caller's stream.  0 = by batch size (1 below
+                          * 60 Mpixel, 2 up to 400, above that ranges of about 130 Mpixel, at most 16), 1 = no split */
     int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
                           * 0 = default (16384 bits' worth, at least 4, at most 32), -1 = none, 1..48 = that many.  Too little warm-up is
                           * never wrong, only slower: hjd_batch_finish then re-synchronises from the host. */

@@ -9,7 +9,7 @@ python3 tools/valu_mix.py $P/valu_mix.json > /dev/null
 cp $(ls -t $(find $O/${T}_stats -name "*kernel_stats.csv") | head -1) $P/${T}_kernel_stats.csv   # the newest: gpurun merges every call's files into the same local directory
 grep '^{"metric"' $O/${T}_stats.log | tail -1 > $P/${T}_bench_under_rocprof.json
 tail -1 $O/${T}_bench.json > $P/${T}_bench.json
-for f in config3_bench photo_bench bench_batch96; do [ -s $O/${T}_$f.json ] && tail -1 $O/${T}_$f.json > $P/${T}_$f.json; done
+for f in config3_bench config3_one_batch config3_four_batches photo_bench bench_batch96; do [ -s $O/${T}_$f.json ] && tail -1 $O/${T}_$f.json > $P/${T}_$f.json; done
 [ -s $O/${T}_config5_bench.json ] && grep '^{' $O/${T}_config5_bench.json > $P/${T}_config5_bench.json
 for f in sampling_throughput restart_stages small_batch_latency small_images convert_walltime host_prepare sync_stats uniform_frames partly_uniform timeline soak; do
   [ -s $O/${T}_$f.txt ] && grep -v "amdgpu.ids" $O/${T}_$f.txt > $P/${T}_$f.txt

@@ -17,7 +17,10 @@ if [ "$PART" = a ]; then
   python3 tools/timeline.py $O/${TAG}_tl > $O/${TAG}_timeline.txt; rm -rf $O/${TAG}_tl; cat $O/${TAG}_timeline.txt
 fi
 if [ "$PART" = b ]; then
-  python3 bench.py --width 1920 --height 1080 --batch 1024 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_config3_bench.json
+  # config 3: sixteen batches of 64 on four caller streams; four batches of 256 (each split by the library); ONE batch of 1024 on one stream
+  python3 bench.py --width 1920 --height 1080 --batch 1024 --steps 5 --warmup 1 --launches-per-stream 4 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_config3_bench.json
+  python3 bench.py --width 1920 --height 1080 --batch 1024 --steps 5 --warmup 1 --internal-streams -1 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_config3_one_batch.json
+  python3 bench.py --width 1920 --height 1080 --batch 1024 --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end 2>/dev/null | python3 -c "$J" > $O/${TAG}_config3_four_batches.json
   rm -f $O/${TAG}_config5_bench.json
   for m in "--caller-streams 4" "--caller-streams 4 --hostile" "--caller-streams 1 --internal-streams 0" "--caller-streams 1 --internal-streams 0 --hostile" "--caller-streams 2" "--caller-streams 1 --internal-streams 4" "--caller-streams 4 --images 512"; do
     python3 tools/config5_bench.py $m 2>/dev/null | python3 -c "$J" >> $O/${TAG}_config5_bench.json
