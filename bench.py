@@ -208,6 +208,7 @@ def main():
                          "with per-image optimised Huffman tables — not the driver's workload, a second data point")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images per GPU, replicated to fill its share (16: profiles/r04_bench_distinct16.json)")
     ap.add_argument("--subseq-bits", type=int, default=0)
+    ap.add_argument("--auto-split", action="store_true", help="hjd_options.streams = 0 (the library's own choice by batch size) beside the caller streams")
     ap.add_argument("--launches-per-stream", type=int, default=1, help="batches per caller stream and step (the rank's share is dealt to streams x this many batches)")
     ap.add_argument("--streams", type=int, default=4, help="split the per-GPU share over this many HIP streams")
     ap.add_argument("--internal-streams", type=int, default=0,
@@ -282,7 +283,7 @@ def main():
         with torch.cuda.stream(ts):
             torch.zeros(1, device="cuda:%d" % local_rank)
     torch.cuda.synchronize()
-    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=0 if args.internal_streams < 0 else max(1, args.internal_streams))  # 1 = no split inside the library, 0 = the library's choice
+    dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=0 if (args.internal_streams < 0 or args.auto_split) else max(1, args.internal_streams))  # 1 = no split inside the library, 0 = the library's choice
     if args.content == "photo":
         import numpy as np
         pb = dec.prepare([open(os.path.join(ROOT, "tests", "golden", "Lenna.jpg"), "rb").read()], hjd.OUT_RGB)

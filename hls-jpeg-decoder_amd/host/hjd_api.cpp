@@ -1476,7 +1476,14 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
         b->callers_seen = distinct;
     }
     if (b->epoch == 0xFFFFFFFFu) b->epoch = 0;
-    if (names || b->ranges.size() <= 1) {
+    // With three or more caller streams in flight (callers_seen) the batch runs whole, on the caller's stream: the other runs are
+    // what this one overlaps with.  Its ranges one behind the other on that stream were measured too — 64 x 4K as four batches of
+    // sixteen on four caller streams 328 Gpixel/s, each batch in two ranges of eight 285; config 3 as four batches of 256, each in
+    // four ranges, 260 against 295 whole: the limit of two synchronisation kernels at a time hands out its turns in the order of
+    // the host's calls, and a stream's four ranges take four turns in a row.  A caller with large batches deals them to its
+    // streams in pieces of about 130 Mpixel itself (bench.py --launches-per-stream: config 3 as sixteen batches 310-314).
+    const bool whole = names || b->ranges.size() <= 1 || b->callers_seen >= 3;
+    if (whole) {
         hjd_batch::Range all{};
         all.i0 = 0;
         all.i1 = b->nimg;
@@ -1498,19 +1505,18 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     // The ranges are dealt round robin to at most four streams — the caller's and the decoder's three (a process has four hardware
     // queues) — and run one behind the other on each: a batch of 2 Gpixel is sixteen ranges of the size that
     // overlaps best (about 130 Mpixel: the headline's launches), four at a time, like a caller that deals sixteen batches to four
-    // streams (BASELINE config 3 as sixteen batches on four caller streams 314 Gpixel/s, as four 286).  With three or more caller
-    // streams in flight (callers_seen) everything stays on the caller's stream: the other runs are what this one overlaps with.
+    // streams (BASELINE config 3 as ONE batch on one caller stream: 302 Gpixel/s in sixteen ranges, 274 in three).
     // Ranges are enqueued in order; with HJD_STAGGER range k's synchronisation waits for range k-1's (or for its final pass).
     const int stagger = from_resync ? 0 : b->dec->stagger;
     const size_t nr = b->ranges.size();
-    const size_t nq = b->callers_seen >= 3 ? 1 : (nr < 4 ? nr : 4);
-    if (nq > 1) HIPCHK(hipEventRecord(b->fork_ev, s));
+    const size_t nq = nr < 4 ? nr : 4;
+    HIPCHK(hipEventRecord(b->fork_ev, s));
     for (size_t k = 0; k < nr; k++) {
         const size_t q = k % nq;
         hipStream_t sk = q ? b->dec->lib_streams[q - 1] : s;
         if (q && k < nq) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0)); // a stream's first range of this run
         int rc = range_enqueue(b, b->ranges[k], sk, from_resync, nullptr, nullptr, nullptr,
-                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, nq > 1 ? k : nr);
+                               (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, k);
         if (rc) return rc;
     }
     for (size_t q = 1; q < nq; q++) {

@@ -120,7 +120,7 @@ typedef struct hjd_options {
     int streams;         /* image ranges a batch is split into.  The ranges are dealt round robin to at most four HIP streams (the caller's
                           * and three of the decoder's, forked from and joined to the caller's inside every run) and run one behind the
                           * other on each: one range's latency-bound synchronisation overlaps another's IDCT.  With three or more caller
-                          * streams in flight on the decoder all ranges stay on the caller's stream.  0 = by batch size (1 below
+                          * streams in flight on the decoder a batch runs whole, on the caller's stream.  0 = by batch size (1 below
                           * 60 Mpixel, 2 up to 400, above that ranges of about 130 Mpixel, at most 16), 1 = no split */
     int sync_overlap;    /* warm-up subsequences every synchronisation wave decodes before the ones it owns:
                           * 0 = default (16384 bits' worth, at least 4, at most 32), -1 = none, 1..48 = that many.  Too little warm-up is
