@@ -367,8 +367,8 @@ __device__ __forceinline__ void write_core(const EntropyLds &L, const uint32_t *
                 e = 16u; // skip 16 bits: any progress will do, the result is flagged
             }
         }
-        // e = length | value bits << 5 | advance << 9
-        const uint32_t len = e & 31u, s = (e >> 5) & 15u, adv = e >> 9;
+        // e = code length + value bits | value bits << 5 | advance << 9
+        const uint32_t s = (e >> 5) & 15u, adv = e >> 9, len = (e & 31u) - s;
         // value bits + DetermineSign (loadjpg.cpp:396-409): v < 2^(s-1), i.e. leading value bit 0, means v - (2^s - 1)
         const uint32_t t = win << len;
         const uint32_t vb = (t >> 1) >> (31u - s);
@@ -644,9 +644,13 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
     const uint32_t st4 = stride * 4u;
     const uint4 cur = lds_load<uint4>(mt4_addr + m * 16u);
     uint32_t acb = cur.y, tb = z ? cur.y : cur.x, mi = cur.z;
-    uint32_t pend = end, zhi = 0u, bfirst = W.bfirst, bdc = W.bdc, tag = W.tag;
+    // block and record numbers run relative to the workgroup's first inside the loop: the entry staging is indexed by them as they are
+    const uint32_t b0 = W.b0, r0 = W.r0;
+    uint32_t pend = end, zhi = 0u, bfirst = W.bfirst == 0xFFFFFFFFu ? 0xFFFFFFFFu : W.bfirst - r0, bdc = W.bdc, tag = W.tag;
+    nblk -= b0;
+    nrec -= r0; // (r0 is a multiple of HJD_REC_RUN: the workgroups' totals are sums of rounded runs)
     const uint32_t ringa = lds_addr(W.ring), enta = lds_addr(W.ent), secm = sec_addr - 2u * HJD_SEC_SIZE;
-    const uint32_t b0 = W.b0, r0 = W.r0, reccap = W.rec_cap, nblocks = W.nblocks;
+    const uint32_t reccap = W.rec_cap > r0 ? W.rec_cap - r0 : 0u, nblocks = W.nblocks - b0, b0s = b0 << 22;
     uint32_t *const recp = W.rec;
     uint2 *const blkp = W.blk;
     unsigned long long act, isdc, bm, rm, g1, g2, sv0;
@@ -663,18 +667,17 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         "ds_read_b128 " KW_MT ", %[mi]\n\t"                     // next block's tables
         "v_cmp_eq_u32_e64 %[isdc], 0, %[z]\n\t"
         "s_waitcnt lgkmcnt(2)\n\t"
-        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, " KW_LEN "\n\t"
+        "v_and_b32_e32 " KW_TOT ", 31, " KW_E "\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, " KW_TOT "\n\t"
         "s_and_b64 %[g1], vcc, exec\n\t"
         "s_cbranch_scc1 4f\n"                                     // a code longer than HJD_LUT_BITS
         "5:\n\t"
-        // e = length | value bits << 5 | advance << 9; value bits + DetermineSign (loadjpg.cpp:396-409)
+        // e = code length + value bits | value bits << 5 | advance << 9; value bits + DetermineSign (loadjpg.cpp:396-409)
         "v_bfe_u32 " KW_S ", " KW_E ", 5, 4\n\t"
         "v_lshrrev_b32_e32 " KW_ADV ", 9, " KW_E "\n\t"
-        "v_add_u32_e32 " KW_TOT ", " KW_LEN ", " KW_S "\n\t"
-        "v_lshlrev_b32_e32 " KW_T ", " KW_LEN ", " KW_WIN "\n\t"
         "v_sub_u32_e32 " KW_OFF ", 32, " KW_TOT "\n\t"
         "v_bfe_u32 " KW_VAL ", " KW_WIN ", " KW_OFF ", " KW_S "\n\t"
+        "v_bfe_i32 " KW_T ", " KW_WIN ", " KW_OFF ", " KW_S "\n\t" // the same bits, sign-extended: negative = leading value bit set
         "v_lshl_add_u32 " KW_K ", -1, " KW_S ", 1\n\t"          // 1 - 2^s
         "v_cmp_gt_i32_e32 vcc, 0, " KW_T "\n\t"                 // leading value bit set: the value as it is
         "v_cndmask_b32_e64 " KW_K ", " KW_K ", 0, vcc\n\t"
@@ -709,7 +712,7 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         "ds_read2st64_b32 " KW_R23 ", %[ringa] offset0:%[c2] offset1:%[c3]\n\t"
         "ds_read2st64_b32 " KW_R45 ", %[ringa] offset0:%[c4] offset1:%[c5]\n\t"
         "ds_read2st64_b32 " KW_R67 ", %[ringa] offset0:%[c6] offset1:%[c7]\n\t"
-        "v_lshlrev_b32_e32 " KW_GO ", 2, %[nrec]\n\t"
+        "v_add_lshl_u32 " KW_GO ", %[nrec], %[r0], 2\n\t"
         "s_waitcnt lgkmcnt(2)\n\t"
         "global_store_dwordx4 " KW_GO ", " KW_R03 ", %[recp] offset:-28\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -719,22 +722,20 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         "v_add_u32_e32 %[nrec], 1, %[nrec]\n\t"
         "s_mov_b64 exec, %[bm]\n\t"                               // ---- end of block: next block (DecodeMCU order, loadjpg.cpp:945-997)
         "v_cmp_ne_u32_e32 vcc, -1, %[bfirst]\n\t"                 // (all ones: the block began in an earlier span, no entry from here)
-        "v_sub_u32_e32 " KW_TI ", %[nblk], %[b0]\n\t"
-        "v_sub_u32_e32 " KW_REL ", %[bfirst], %[r0]\n\t"
-        "v_cmp_gt_u32_e64 %[g1], %[entcap], " KW_TI "\n\t"
-        "v_cmp_gt_u32_e64 %[g2], %[m16], " KW_REL "\n\t"
+        "v_cmp_gt_u32_e64 %[g1], %[entcap], %[nblk]\n\t"        // (block and record numbers are relative to the workgroup's first here)
+        "v_cmp_gt_u32_e64 %[g2], %[m16], %[bfirst]\n\t"
         "s_and_b64 %[g1], %[g1], %[g2]\n\t"
         "s_andn2_b64 %[g2], vcc, %[g1]\n\t"
         "s_cbranch_scc1 9f\n"                                     // more blocks or records than the staging holds: straight out
         "10:\n\t"
-        "v_lshl_or_b32 " KW_EV ", %[bdc], 16, " KW_REL "\n\t"
-        "v_lshl_add_u32 " KW_EA ", " KW_TI ", 2, %[enta]\n\t"
+        "v_lshl_or_b32 " KW_EV ", %[bdc], 16, %[bfirst]\n\t"
+        "v_lshl_add_u32 " KW_EA ", %[nblk], 2, %[enta]\n\t"
         "s_and_b64 exec, vcc, %[g1]\n\t"
         "ds_write_b32 " KW_EA ", " KW_EV "\n\t"
         "s_mov_b64 exec, %[bm]\n\t"
         "v_mov_b32_e32 %[bfirst], -1\n\t"
         "v_add_u32_e32 %[nblk], 1, %[nblk]\n\t"
-        "v_lshlrev_b32_e32 %[tag], 22, %[nblk]\n\t"
+        "v_lshl_add_u32 %[tag], %[nblk], 22, %[b0s]\n\t"
         "v_and_b32_e32 %[tag], %[tagm], %[tag]\n\t"
         "v_cmp_eq_u32_e32 vcc, %[nblocks], %[nblk]\n\t"
         "s_and_b64 %[g1], vcc, exec\n\t"
@@ -768,12 +769,12 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         "v_cmp_ne_u32_e32 vcc, 0, " KW_T "\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cndmask_b32_e32 " KW_E ", 0, " KW_A ", vcc\n\t"
-        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, " KW_LEN "\n\t"
+        "v_and_b32_e32 " KW_TOT ", 31, " KW_E "\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, " KW_TOT "\n\t"
         "v_cndmask_b32_e64 " KW_T ", 0, 1, vcc\n\t"
         "v_or_b32_e32 %[flags], %[flags], " KW_T "\n\t"         // HJD_FLAG_BAD_CODE
         "v_cndmask_b32_e64 " KW_E ", " KW_E ", 16, vcc\n\t"     // skip 16 bits: any progress will do, the result is flagged
-        "v_and_b32_e32 " KW_LEN ", 31, " KW_E "\n\t"
+        "v_and_b32_e32 " KW_TOT ", 31, " KW_E "\n\t"
         "s_mov_b64 exec, %[act]\n\t"
         "s_branch 5b\n"
         "8:\n\t"                                                  // ---- bursts past the record space are not stored (g1: those lanes)
@@ -784,18 +785,18 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         "s_branch 6b\n"
         "9:\n\t"                                                  // ---- block entries that do not fit the staging (g2: those lanes)
         "s_mov_b64 exec, %[g2]\n\t"
-        "v_mov_b32_e32 " KW_R0 ", %[bfirst]\n\t"
+        "v_add_u32_e32 " KW_R0 ", %[bfirst], %[r0]\n\t"
         "v_and_b32_e32 " KW_R1 ", %[m16], %[bdc]\n\t"
-        "v_lshlrev_b32_e32 " KW_GO ", 3, %[nblk]\n\t"
+        "v_add_lshl_u32 " KW_GO ", %[nblk], %[b0], 3\n\t"
         "s_nop 0\n\t"
         "global_store_dwordx2 " KW_GO ", " KW_R01 ", %[blkp]\n\t"
         "s_mov_b64 exec, %[bm]\n\t"
         "s_branch 10b\n"
         "11:\n\t"                                                 // ---- the last block (g1: those lanes): end of its records; what follows is not looked at
         "s_mov_b64 exec, %[g1]\n\t"
-        "v_mov_b32_e32 " KW_R0 ", %[nrec]\n\t"
+        "v_add_u32_e32 " KW_R0 ", %[nrec], %[r0]\n\t"
         "v_mov_b32_e32 " KW_R1 ", 0\n\t"
-        "v_lshlrev_b32_e32 " KW_GO ", 3, %[nblk]\n\t"
+        "v_add_lshl_u32 " KW_GO ", %[nblk], %[b0], 3\n\t"
         "v_add_u32_e32 %[pend], %[p], " KW_TOT "\n\t"
         "global_store_dwordx2 " KW_GO ", " KW_R01 ", %[blkp]\n\t"
         "s_mov_b64 exec, %[bm]\n\t"
@@ -806,7 +807,7 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
         : [p] "+v"(p), [z] "+v"(z), [sh] "+v"(sh), [hi] "+v"(hi), [lo] "+v"(lo), [nxa] "+v"(nxa), [tb] "+v"(tb), [acb] "+v"(acb), [mi] "+v"(mi),
           [nblk] "+v"(nblk), [nrec] "+v"(nrec), [bfirst] "+v"(bfirst), [bdc] "+v"(bdc), [tag] "+v"(tag), [flags] "+v"(flags), [zhi] "+v"(zhi),
           [pend] "+v"(pend), [act] "=&s"(act), [isdc] "=&s"(isdc), [bm] "=&s"(bm), [rm] "=&s"(rm), [g1] "=&s"(g1), [g2] "=&s"(g2), [sv0] "=&s"(sv0)
-        : [ringa] "v"(ringa), [enta] "v"(enta), [secm] "v"(secm), [slotb] "v"(slot_addr), [st4] "v"(st4), [b0] "v"(b0), [r0] "v"(r0),
+        : [ringa] "v"(ringa), [enta] "v"(enta), [secm] "v"(secm), [slotb] "v"(slot_addr), [st4] "v"(st4), [b0] "v"(b0), [r0] "v"(r0), [b0s] "v"(b0s),
           [reccap] "s"(reccap), [nblocks] "s"(nblocks), [entcap] "s"(ENTCAP), [m16] "s"(0xFFFFu), [tagm] "s"(0x1FC00000u), [recp] "s"(recp),
           [blkp] "s"(blkp), [lb] "n"(32 - HJD_LUT_BITS), [lw] "n"(HJD_LUT_BITS), [sw] "n"(HJD_SEC_BITS), [lgcol] "n"(WGSZ == 256 ? 10 : 8),
           [c0] "n"(0 * U), [c1] "n"(1 * U), [c2] "n"(2 * U), [c3] "n"(3 * U), [c4] "n"(4 * U), [c5] "n"(5 * U), [c6] "n"(6 * U), [c7] "n"(7 * U)
@@ -814,7 +815,9 @@ __device__ __forceinline__ void write_window_plain(uint32_t mt4_addr, uint32_t s
           "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96");
     flags |= (zhi >> 5) & HJD_FLAG_OVERRUN; // zw <= 63 + 15, so bit 6 says it
     m = lds_load<uint32_t>(mi + 12u);       // the block in progress
-    W.bfirst = bfirst;
+    nblk += b0;
+    nrec += r0;
+    W.bfirst = bfirst == 0xFFFFFFFFu ? 0xFFFFFFFFu : bfirst + r0;
     W.bdc = bdc;
     W.tag = tag;
 }

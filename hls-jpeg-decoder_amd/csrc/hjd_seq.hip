@@ -122,10 +122,10 @@ __device__ __forceinline__ bool seq_peek(const SeqReader &r0, const SeqLut *s_lu
         const uint32_t sub = e >> 5;
         e = sub ? ts.sec[sub - 1u][c16 & (HJD_SEC_SIZE - 1u)] : 0u;
     }
-    len = e & 31u;
-    size = (e >> 5) & 15u;
+    size = (e >> 5) & 15u; // e = code length + value bits | value bits << 5 | advance << 9
+    len = (e & 31u) - size;
     adv = e >> 9;
-    return len != 0u;
+    return (e & 31u) != 0u;
 }
 
 // ONE block as ProcessHuffmanBlock decodes it (loadjpg.cpp:499-863) behind its block-start check, which is the caller's:

@@ -241,7 +241,7 @@ static bool build_table(HjdTableSet &ts, int ti, const hjd_huff_spec &h, bool is
                     else adv = r == 0 ? 64 : (r == 15 ? 16 : 0);
                 }
                 const uint16_t e = sync_form ? (uint16_t)((k + s) | (adv << 5) | ((!is_dc && s) ? 1u << 14 : 0u)) // synchronisation form
-                                             : (uint16_t)(k | (s << 5) | (adv << 9));
+                                             : (uint16_t)((k + s) | (s << 5) | (adv << 9)); // (k + s <= 31: the walk admits 16-bit codes, 15 value bits)
                 if ((unsigned)k <= bits) {
                     const unsigned lo = code << (bits - k), cnt = 1u << (bits - k);
                     for (unsigned q = 0; q < cnt; q++) {
