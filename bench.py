@@ -248,17 +248,30 @@ def main():
     hjd = importlib.import_module("hls-jpeg-decoder_amd")
     shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
     seen = 1
-    if world > 1:
+    # HJD_BENCH_GROUP_AT_ONE=1 (rehearsal, not used by the driver): a process group even for ONE rank, so that the RCCL branch —
+    # eager communicator on the rank's device, barrier, all-reduce, all-gather — executes on a one-GPU box
+    grouped = world > 1 or os.environ.get("HJD_BENCH_GROUP_AT_ONE") == "1"
+
+    def join_group():
         # explicit timeout; RCCL comes up eagerly on this rank's device (a rank that cannot reach its peers fails HERE);
         # the backend really in use and the number of ranks that answered an all-reduce of ones go into the JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = shard.fail_fast("init_process_group", shard.init_group, backend, local_rank, PG_TIMEOUT_S())
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        be = shard.fail_fast("init_process_group", shard.init_group, backend, local_rank, PG_TIMEOUT_S())
         assert dist.get_world_size() == args.gpus
-        seen = shard.fail_fast("rank count", shard.ranks_seen, "cuda" if backend == "nccl" else "cpu")
-        if seen != world:
-            raise SystemExit("bench: %d ranks answered, %d expected" % (seen, world))
-    else:
+        n = shard.fail_fast("rank count", shard.ranks_seen, "cuda" if be == "nccl" else "cpu")
+        if n != world:
+            raise SystemExit("bench: %d ranks answered, %d expected" % (n, world))
+        return be, n
+    # The group is joined AFTER the caller's streams and the decoder's exist (below) unless HJD_BENCH_GROUP_EARLY=1: RCCL creates
+    # streams of its own, and a stream takes its hardware queue at its first command — the four queues of the process go to the
+    # streams that carry the kernels, RCCL's (idle inside the timed region) share.
+    if not grouped:
         backend = "none"
+    elif os.environ.get("HJD_BENCH_GROUP_EARLY") == "1":
+        backend, seen = join_group()
 
     # ONE global batch of world x batch images, image g = synthetic source number g mod (distinct x world);
     # every rank computes the same partition (cost = pixels) and decodes its own shard.
@@ -284,6 +297,8 @@ def main():
             torch.zeros(1, device="cuda:%d" % local_rank)
     torch.cuda.synchronize()
     dec = hjd.Decoder(local_rank, subseq_bits=args.subseq_bits, streams=0 if (args.internal_streams < 0 or args.auto_split) else max(1, args.internal_streams))  # 1 = no split inside the library, 0 = the library's choice
+    if grouped and os.environ.get("HJD_BENCH_GROUP_EARLY") != "1":
+        backend, seen = join_group()
     if args.content == "photo":
         import numpy as np
         pb = dec.prepare([open(os.path.join(ROOT, "tests", "golden", "Lenna.jpg"), "rb").read()], hjd.OUT_RGB)
@@ -318,7 +333,7 @@ def main():
     streams = [tstreams[j % nstreams].cuda_stream for j in range(ns)]
 
     def barrier():
-        if world > 1:  # a failed barrier ends this rank (non-zero) at once; the launcher ends the others
+        if grouped:  # a failed barrier ends this rank (non-zero) at once; the launcher ends the others
             if backend == "nccl":
                 shard.fail_fast("barrier", dist.barrier, device_ids=[local_rank])
             else:
@@ -414,8 +429,8 @@ def main():
         e2e = dec.decode_host_pipelined_bench(jpgs, W, H)
 
     adev = "cuda" if backend == "nccl" else "cpu"
-    per_rank = shard.fail_fast("per-rank times", shard.gather_per_rank, rank, local_rank, dt, args.steps, device=adev)  # before MAX replaces dt
-    dt, total_pixels = shard.fail_fast("clock agreement", shard.agree, dt, pixels, device=adev)  # MAX of time, SUM of pixels
+    per_rank = shard.fail_fast("per-rank times", shard.gather_per_rank, rank, local_rank, dt, args.steps, device=adev, alone_too=grouped)  # before MAX replaces dt
+    dt, total_pixels = shard.fail_fast("clock agreement", shard.agree, dt, pixels, device=adev, alone_too=grouped)  # MAX of time, SUM of pixels
     spread_dt = [shard.fail_fast("clock agreement", shard.agree, x, 0.0, device=adev)[0] for x in spread_dt]
 
     if rank == 0:
@@ -559,7 +574,7 @@ def main():
     for b in batches:
         b.close()
     dec.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

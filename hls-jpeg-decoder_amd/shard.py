@@ -72,11 +72,12 @@ def fail_fast(what, fn, *args, **kw):
         os._exit(3)
 
 
-def agree(elapsed_s, units, device=None):
-    """(max over ranks of elapsed_s, sum over ranks of units).  No-op without a process group."""
+def agree(elapsed_s, units, device=None, alone_too=False):
+    """(max over ranks of elapsed_s, sum over ranks of units).  No-op without a process group, and for a group of one rank
+    unless `alone_too` (a rehearsal of the collectives on a one-GPU box)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not alone_too):
         return float(elapsed_s), float(units)
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -85,13 +86,13 @@ def agree(elapsed_s, units, device=None):
     return float(t.item()), float(u.item())
 
 
-def gather_per_rank(rank, device_index, elapsed_s, steps, device=None):
+def gather_per_rank(rank, device_index, elapsed_s, steps, device=None, alone_too=False):
     """Every rank's own step time, for rank 0's JSON line: [{"rank", "device", "ms_per_step"}, ...] in rank order.  MAX-of-time
     (agree) hides which rank was the slow one; a straggler shows here.  One all-gather of three numbers, outside the timed region."""
     import torch
     import torch.distributed as dist
     mine = [float(rank), float(device_index), float(elapsed_s) / max(1, int(steps)) * 1e3]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not alone_too):
         rows = [mine]
     else:
         t = torch.tensor(mine, dtype=torch.float64, device=device)

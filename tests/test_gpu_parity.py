@@ -1002,6 +1002,28 @@ def test_bench_launches_its_own_ranks(tmp_path, world):
     assert abs(line["value"] * 1e6 * line["ms_per_step"] * 1e-3 - px) / px < 0.02
 
 
+def test_bench_single_rank_over_rccl():
+    """The RCCL branch of the multi-rank plumbing, executed on the one GPU a builder's box has: a process group of ONE rank over
+    backend "nccl" (= RCCL; HJD_BENCH_GROUP_AT_ONE=1), i.e. the eager communicator on the rank's device, the barriers around the
+    timed region, the all-reduce of ones, the all-gather of the per-rank times and the MAX / SUM agreement all run through RCCL
+    with tensors on the device — exactly the calls N > 1 ranks make.  The line must say backend nccl and outputs must be right."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HJD_BENCH_GROUP_AT_ONE="1", HJD_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--width", "1920", "--height", "1080", "--distinct", "2", "--streams", "2",
+                        "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["backend"] == "nccl", (line["backend"], r.stderr[-2000:])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["parity"] == "ok"
+    assert [p["rank"] for p in line["per_rank"]] == [0] and abs(line["per_rank"][0]["ms_per_step"] - line["ms_per_step"]) < 1e-2
+
+
 def test_two_host_threads_share_one_decoder(hjd, dec, golden):
     """SURVEY §8b asks for a thread-safe ABI: two host threads drive ONE decoder, each with batches of its own on a stream
     of its own (prepare / run / finish / download interleave freely; ctypes releases the GIL inside the calls), while a third
