@@ -218,7 +218,11 @@ def main():
     ap.add_argument("--no-stage-events", action="store_true", help="diagnostic: no hipEvents between the kernels of the timed steps")
     ap.add_argument("--stage-events", choices=("one", "all"), default="one",
                     help="which launches of a step carry stage hipEvents in the reported region: those of ONE stream (default: every "
-                         "step has one instrumented launch — the events cost a launch 3-4 %%, profiles/r05_stage_events.txt) or of all")
+                         "step has one instrumented launch) or of all (no measurable difference: profiles/r05_warmup.txt)")
+    ap.add_argument("--preheat-ms", type=float, default=150.0,
+                    help="untimed steps run for this long BEFORE the --warmup steps: the GPU comes out of the minutes of host-side setup at its "
+                         "idle clocks and needs some tens of milliseconds of load to reach its working state (a 5-step warm-up is 8 ms); "
+                         "0 = none.  Reported in the line as `preheat`.")
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of --steps steps after the reported one: their values are listed as `spread`")
     args = ap.parse_args()
 
@@ -349,6 +353,15 @@ def main():
     # statuses fetched and 340 events created in between, the timed region began on a GPU that had been idle for a millisecond
     # or two (the first region of a run was 5 % below the following ones, with or without stage events).
     timed_batches = [] if (args.internal_streams > 1 or args.internal_streams < 0 or args.no_stage_events) else (batches[:1] if args.stage_events == "one" else batches)
+    # Pre-heat (untimed, before the W warm-up steps): the same step, repeated until --preheat-ms have passed.  The setup above is
+    # seconds of host work during which the GPU sits at its idle clocks; measured (round 5): with --warmup 5 the timed region ran
+    # 4-5 % below the regions after it, with --warmup 40 level with them, with or without stage events (profiles/r05_warmup.txt).
+    preheat_steps, preheat_t0 = 0, time.perf_counter()
+    while (time.perf_counter() - preheat_t0) * 1e3 < args.preheat_ms:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        preheat_steps += 5
     for b in timed_batches:
         b.enable_timing(args.steps + args.warmup)
     for _ in range(args.warmup):
@@ -560,6 +573,8 @@ def main():
             "stage_ms_isolated": {n: round(ms, 4) for n, ms in stages_iso},
             "stage_ms_overlapped": {n: round(ms, 4) for n, ms in stages_ovl},
             "timed_runs": runs,
+            "preheat": {"ms": args.preheat_ms, "steps": preheat_steps,
+                        "note": "untimed steps before the --warmup steps, until the GPU has left its idle clocks; --preheat-ms 0 turns them off"},
             "spread": {"further_regions_of_%d_steps" % args.steps: [round(total_pixels * args.steps / x / 1e6, 1) for x in spread_dt],
                        "note": "same process, same batches, measured after the reported region; box to box the same build differs by a few per cent more"},
             "parity": parity,

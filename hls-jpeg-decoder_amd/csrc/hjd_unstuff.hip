@@ -168,7 +168,20 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[HJD_UNSTUFF_CHUNK + 32]; // the chunk's kept bytes, MSB-first words
     __shared__ uint32_t s_pos[UNSTUFF_T], s_mk[UNSTUFF_T], s_sum[2];
     const uint32_t tid = threadIdx.x;
+#ifdef HJD_UNSTUFF_NO_XCD
     const uint32_t c = blockIdx.x + P.off_chunk;
+#else
+    // XCD-aware chunk numbering.  Workgroups are dealt to the eight XCDs round robin (workgroup b runs on XCD b mod 8), each XCD
+    // has its own L2, and two neighbouring chunks write into the same sectors of the transposed stream (the rows at their common
+    // border, at every word k): with chunk = workgroup number those halves of a sector sat in two L2s and reached HBM as two
+    // partial writes (2.5 MB written per 4K image for 1.4 MB of stream).  Here XCD x takes a CONTIGUOUS run of chunks —
+    // the first n mod 8 XCDs one more than the others — so neighbours meet in one L2.
+    uint32_t c;
+    {
+        const uint32_t n = gridDim.x, x = blockIdx.x & 7u, j = blockIdx.x >> 3, q = n >> 3, r = n & 7u;
+        c = x * q + min(x, r) + j + P.off_chunk;
+    }
+#endif
     const int ii = (int)P.map_chunk[c];
     const HjdImage &im = P.img[ii];
     const uint32_t lc = c - im.chunk0;
@@ -268,8 +281,24 @@ __global__ __launch_bounds__(UNSTUFF_T) void k_unstuff_write(HjdParams P)
     {
         const uint32_t endp = base + total;                 // one past the chunk's last kept byte
         const uint32_t w_first = (base + 3u) >> 2, w_last = endp >> 2; // whole words [w_first, w_last)
+#ifdef HJD_UNSTUFF_LINEAR // round 2-5 form: consecutive lanes take consecutive words of ONE row — 64 stores to 64 different 256-byte lines
         for (uint32_t wq = w_first + tid; wq < w_last; wq += UNSTUFF_T)
             put_word_or_byte(wq, *reinterpret_cast<const uint32_t *>(&s_bytes[(wq << 2) - wbase]), -1);
+#else
+        // Consecutive lanes take the SAME word k of consecutive rows (subsequences): in the transposed layout those are
+        // neighbouring addresses, so the n rows a chunk touches leave a wave as runs of n x 4 bytes — one or two sectors — instead
+        // of n lone 4-byte stores per k (a chunk of 4 KiB is 8 rows of 4096 bits, 16 of 2048).  t -> (row, k) by a multiplication
+        // with the reciprocal of n (exact for t < 2^16).
+        if (w_last > w_first) {
+            const uint32_t ra = w_first >> lw, n = ((w_last - 1u) >> lw) - ra + 1u;
+            const uint32_t rcp = n > 1u ? 0xFFFFFFFFu / n + 1u : 0u, cells = n << lw;
+            for (uint32_t t = tid; t < cells; t += UNSTUFF_T) {
+                const uint32_t k = n > 1u ? __umulhi(t, rcp) : t, row = ra + (t - k * n);
+                const uint32_t wq = (row << lw) + k;
+                if (wq >= w_first && wq < w_last) put_word_or_byte(wq, *reinterpret_cast<const uint32_t *>(&s_bytes[(wq << 2) - wbase]), -1);
+            }
+        }
+#endif
         // bytes of the partial words: head = [base, min(4*w_first, endp)), tail = [4*w_last, endp) when w_last >= w_first
         if (tid < 4) {
             const uint32_t q = base + tid;

@@ -125,8 +125,6 @@ struct hjd_decoder {
                            // unless a workgroup's 16 kbit of warm-up were not enough).  Default none: k_write checks the
                            // induction step for every subsequence and hjd_batch_finish repairs from the host
     uint32_t sync_overlap = 8; // warm-up subsequences per synchronisation workgroup
-    unsigned evf_timing = 0u;                     // flags of the stage-timing events (experiment knob HJD_EVF_T)
-    unsigned evf_sync = hipEventDisableTiming;    // flags of the events that order launches across streams (HJD_EVF_S)
     uint32_t phase_words = 16; // words of a subsequence staged in LDS at a time = the window one k_write lane decodes
     int streams = 0;           // image ranges a batch is split into (hjd_options.streams); 0 = by batch size
     // Front-end concurrency limit (HJD_SYNC_CONC): the synchronisation kernel is a latency chain that
@@ -341,8 +339,6 @@ extern "C" hjd_decoder *hjd_decoder_create(int device, const hjd_options *opt)
     if (const char *ec = getenv("HJD_SYNC_CONC")) d->sync_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *ec = getenv("HJD_IDCT_CONC")) d->idct_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     d->no_side = getenv("HJD_NO_SIDE") != nullptr;
-    if (const char *ef = getenv("HJD_EVF_T")) d->evf_timing = (unsigned)strtoul(ef, nullptr, 0); // experiment knobs: hipEvent flags
-    if (const char *ef = getenv("HJD_EVF_S")) d->evf_sync = (unsigned)strtoul(ef, nullptr, 0) | hipEventDisableTiming;
     if (const char *ec = getenv("HJD_WRITE_CONC")) d->write_conc = atoi(ec) < 0 ? 0 : (atoi(ec) > 8 ? 8 : atoi(ec));
     if (const char *es = getenv("HJD_STAGGER")) d->stagger = atoi(es) < 0 ? 0 : (atoi(es) > 2 ? 2 : atoi(es)); // experiment knob
     const char *e = getenv("HJD_SUBSEQ_BITS");
@@ -1089,8 +1085,8 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         if (side_needed) {
             while (b->small_side.size() < b->ranges.size()) {
                 hjd_batch::SideStream ss;
-                HIPCHK(hipEventCreateWithFlags(&ss.fork, b->dec->evf_sync));
-                HIPCHK(hipEventCreateWithFlags(&ss.done, b->dec->evf_sync));
+                HIPCHK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
                 b->small_side.push_back(ss);
             }
         }
@@ -1106,12 +1102,12 @@ static int batch_build(hjd_batch *b, const std::vector<hjd_jpeg_data> &parsed, h
         if (b->ranges.size() > 1) {
             while (b->join_ev.size() < b->ranges.size()) { // (the ranges' streams are the decoder's: batch_enqueue)
                 hipEvent_t e = nullptr, se = nullptr;
-                HIPCHK(hipEventCreateWithFlags(&e, b->dec->evf_sync));
-                HIPCHK(hipEventCreateWithFlags(&se, b->dec->evf_sync));
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&se, hipEventDisableTiming));
                 b->join_ev.push_back(e);
                 b->stagger_ev.push_back(se);
             }
-            if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, b->dec->evf_sync));
+            if (!b->fork_ev) HIPCHK(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         }
     }
     return HJD_OK;
@@ -1358,7 +1354,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
             hjd_decoder *d = b->dec;
             std::lock_guard<std::mutex> lk(d->conc_mu);
             const uint64_t k = d->conc_runs++;
-            if (!d->conc_ev[k & 15] && hipEventCreateWithFlags(&d->conc_ev[k & 15], d->evf_sync) != hipSuccess) return HJD_ERR_INTERNAL;
+            if (!d->conc_ev[k & 15] && hipEventCreateWithFlags(&d->conc_ev[k & 15], hipEventDisableTiming) != hipSuccess) return HJD_ERR_INTERNAL;
             if (k >= (uint64_t)d->sync_conc && hipStreamWaitEvent(s, d->conc_ev[(k - d->sync_conc) & 15], 0) != hipSuccess) return HJD_ERR_INTERNAL;
             conc_record = d->conc_ev[k & 15];
         }
@@ -1388,7 +1384,7 @@ static int range_enqueue(hjd_batch *b, const hjd_batch::Range &r, hipStream_t s,
         hjd_decoder *d = b->dec;
         std::lock_guard<std::mutex> lk(d->conc_mu);
         const uint64_t k = runs++;
-        if (!evs[k & 15] && hipEventCreateWithFlags(&evs[k & 15], d->evf_sync) != hipSuccess) return HJD_ERR_INTERNAL;
+        if (!evs[k & 15] && hipEventCreateWithFlags(&evs[k & 15], hipEventDisableTiming) != hipSuccess) return HJD_ERR_INTERNAL;
         if (k >= (uint64_t)limit && hipStreamWaitEvent(s, evs[(k - limit) & 15], 0) != hipSuccess) return HJD_ERR_INTERNAL;
         rec = evs[k & 15];
         return HJD_OK;
@@ -1558,7 +1554,7 @@ extern "C" int hjd_batch_enable_timing(hjd_batch *b, int max_runs)
     b->tev.resize(max_runs);
     for (auto &v : b->tev) {
         v.resize(HJD_MAX_STAGES + 1);
-        for (auto &e : v) HIPCHK(hipEventCreateWithFlags(&e, b->dec->evf_timing));
+        for (auto &e : v) HIPCHK(hipEventCreate(&e));
     }
     b->tev_cap = max_runs;
     return HJD_OK;
