@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--no-stage-events", action="store_true")
     ap.add_argument("--dirty-mode", type=int, default=0, help="1: restart streams outside the clean-resync domain are refused (no emulation launches)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: the runtime's default, 4)")
+    ap.add_argument("--preheat-ms", type=float, default=150.0, help="untimed steps before the timed region (0: none)")
     ap.add_argument("--images", type=int, default=128, help="batch size (a multiple of 32: the 32 distinct images repeated)")
     a = ap.parse_args()
     sizes = [(3840, 2160), (1920, 1080), (1280, 720), (1000, 700), (777, 333), (640, 480), (512, 512), (250, 187)]
@@ -87,6 +88,13 @@ def main():
     torch.cuda.synchronize()
     for b, sh in zip(batches, streams):
         b.finish(sh)
+    # pre-heat, as bench.py does (profiles/r05_warmup.txt): the GPU needs some tens of milliseconds of load after the seconds of
+    # host-side setup above before it runs at its working clocks
+    pre_t0 = time.perf_counter()
+    while (time.perf_counter() - pre_t0) * 1e3 < a.preheat_ms:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
     internal = a.internal_streams != 1  # stage events use the single-range form of the run: not with a split inside the library
     if not a.no_stage_events and not internal:
         for b in batches:
