@@ -125,3 +125,23 @@ def test_no_kernel_can_leave_its_slab(hjd, header, S):
             assert tile * o.nb <= 3072 and tile <= 512                            # s_lnk[9][3072], s_d[512]
         else:
             assert o.seg_cap == 0 and o.seg_nodes == 0 and o.seg_slab_bytes == 0
+
+
+def test_xcd_aware_chunk_numbering_is_a_bijection():
+    """k_unstuff_write numbers its chunks so that XCD x (workgroup b runs on XCD b mod 8) takes a CONTIGUOUS run of them:
+    chunk = x * (n // 8) + min(x, n % 8) + b // 8 (csrc/hjd_unstuff.hip).  Every chunk must be taken exactly once for every
+    grid size — a chunk left out would leave a hole in the unstuffed stream, one taken twice is a race — and the runs must be
+    contiguous per XCD, which is the point of the numbering.  (The kernel's own arithmetic is exercised by every GPU test; this
+    restates it so that a change there is made on purpose.)"""
+    src = open(os.path.join(ROOT, "hls-jpeg-decoder_amd", "csrc", "hjd_unstuff.hip")).read()
+    assert "c = x * q + min(x, r) + j + P.off_chunk;" in src and "x = blockIdx.x & 7u, j = blockIdx.x >> 3, q = n >> 3, r = n & 7u" in src
+    for n in list(range(1, 300)) + [1023, 1024, 1025, 5199, 5200, 5207, 83200, 83201]:
+        q, r = n >> 3, n & 7
+        taken = [None] * n
+        for b in range(n):
+            x, j = b & 7, b >> 3
+            c = x * q + min(x, r) + j
+            assert 0 <= c < n and taken[c] is None, (n, b, c)
+            taken[c] = x
+        # contiguous per XCD, XCDs in ascending order
+        assert taken == sorted(taken), n
