@@ -1019,6 +1019,8 @@ def test_bench_single_rank_over_rccl():
                         "--no-cpu-baseline", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    if line["backend"] != "nccl" and "RCCL init failed" in r.stderr:  # a box on which RCCL cannot come up at all (shard.init_group fell back to gloo)
+        pytest.skip("RCCL could not be brought up on this box: " + r.stderr[-300:])
     assert line["backend"] == "nccl", (line["backend"], r.stderr[-2000:])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["parity"] == "ok"
     assert [p["rank"] for p in line["per_rank"]] == [0] and abs(line["per_rank"][0]["ms_per_step"] - line["ms_per_step"]) < 1e-2
