@@ -1511,18 +1511,34 @@ static int batch_enqueue(hjd_batch *b, hipStream_t s, bool from_resync, int *nst
     const size_t nr = b->ranges.size();
     const size_t nq = nr < 4 ? nr : 4;
     HIPCHK(hipEventRecord(b->fork_ev, s));
+    // include/hjd.h: work on the library's streams is joined to the caller's before hjd_batch_run returns — also when a launch
+    // fails half-way (the streams forked so far are joined on every way out)
+    size_t forked = 1; // streams 1 .. forked-1 of this run have been given work
+    auto join_forked = [&]() -> int {
+        int rc = HJD_OK;
+        for (size_t q = 1; q < forked; q++)
+            if (hipEventRecord(b->join_ev[q], b->dec->lib_streams[q - 1]) != hipSuccess || hipStreamWaitEvent(s, b->join_ev[q], 0) != hipSuccess)
+                rc = HJD_ERR_INTERNAL;
+        return rc;
+    };
     for (size_t k = 0; k < nr; k++) {
         const size_t q = k % nq;
         hipStream_t sk = q ? b->dec->lib_streams[q - 1] : s;
-        if (q && k < nq) HIPCHK(hipStreamWaitEvent(sk, b->fork_ev, 0)); // a stream's first range of this run
+        if (q && k < nq) { // a stream's first range of this run
+            if (hipStreamWaitEvent(sk, b->fork_ev, 0) != hipSuccess) {
+                (void)join_forked();
+                return HJD_ERR_INTERNAL;
+            }
+            forked = q + 1;
+        }
         int rc = range_enqueue(b, b->ranges[k], sk, from_resync, nullptr, nullptr, nullptr,
                                (stagger && k) ? b->stagger_ev[k - 1] : nullptr, stagger ? b->stagger_ev[k] : nullptr, stagger, k);
-        if (rc) return rc;
+        if (rc) {
+            (void)join_forked();
+            return rc;
+        }
     }
-    for (size_t q = 1; q < nq; q++) {
-        HIPCHK(hipEventRecord(b->join_ev[q], b->dec->lib_streams[q - 1]));
-        HIPCHK(hipStreamWaitEvent(s, b->join_ev[q], 0));
-    }
+    if (join_forked() != HJD_OK) return HJD_ERR_INTERNAL;
     return emulation_enqueue(b, s);
 }
 
