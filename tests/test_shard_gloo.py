@@ -161,3 +161,37 @@ def test_a_rank_that_never_reaches_the_barrier_ends_the_job_within_the_group_tim
     assert "ranks failed" in r.stderr and "barrier failed" in r.stderr
     assert "n_gpus" not in r.stdout
     assert dt < 90, dt
+
+
+def _alone_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = "0"
+    os.environ["WORLD_SIZE"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    shard = importlib.import_module("hls-jpeg-decoder_amd.shard")
+    be = shard.init_group("gloo", None, 60.0)
+    seen = shard.ranks_seen("cpu")
+    skipped = shard.agree(0.25, 7.0, device="cpu")                       # a group of one: no collective by default ...
+    t, u = shard.agree(0.25, 7.0, device="cpu", alone_too=True)          # ... unless asked (the one-GPU rehearsal of the RCCL branch)
+    rows = shard.gather_per_rank(0, 3, 0.5, 10, device="cpu", alone_too=True)
+    q.put((be, seen, skipped, t, u, rows))
+    dist.destroy_process_group()
+
+
+def test_group_of_one_rank_runs_the_collectives_when_asked():
+    """bench.py's HJD_BENCH_GROUP_AT_ONE rehearsal (tests/test_gpu_parity.py::test_bench_single_rank_over_rccl runs it over RCCL on
+    the GPU): with `alone_too` the agreement and the per-rank gather go through the process group even for one rank; here over
+    gloo, so that the helpers' one-rank path is covered without a GPU."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_alone_worker, args=(port, q))
+    p.start()
+    be, seen, skipped, t, u, rows = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert be == "gloo" and seen == 1
+    assert skipped == (0.25, 7.0) and abs(t - 0.25) < 1e-12 and abs(u - 7.0) < 1e-12
+    assert rows == [{"rank": 0, "device": 3, "ms_per_step": 50.0}]
